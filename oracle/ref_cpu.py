@@ -1,0 +1,403 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY, NOT PRODUCT CODE.
+
+A functional fp32 restatement (plain torch CPU ops over a flat state-dict) of the
+encoder -> decoder hot path of mariaalfaroc/omr_a2s_multimodal_transformer.  It is the
+checker for the HIP path: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  The product package never does.
+
+Parity status: PINNED.  The reference ships no tests/golden vectors of its own
+(SURVEY.md section 4), so this file is pinned by ``tests/golden/*.npz`` -- outputs of the
+reference's own modules imported in the build container by ``tests/golden/gen_golden.py``
+(see ``tests/test_oracle_golden.py``).
+
+Every function cites the reference lines it restates (paths relative to the reference
+root).  All dropout layers are identity here (eval-mode / p=0 parity, SURVEY.md section 7
+"Parity under dropout").
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+HEIGHT_REDUCTION = 16  # src/transformer/encoder.py:8
+WIDTH_REDUCTION = 8  # src/transformer/encoder.py:9
+
+
+@dataclass
+class OracleCfg:
+    """Hyper-parameters the reference hard-codes (decoder.py:61-68, model.py:95-96)."""
+
+    d_model: int = 256
+    nhead: int = 4
+    ff_dim: int = 256
+    num_layers: int = 8
+    attn_window: int = -1
+    pad_idx: int = 0
+
+
+# --------------------------------------------------------------------------------------
+# Encoder  (src/transformer/encoder.py)
+# --------------------------------------------------------------------------------------
+
+CONV_STRIDES = ((1, 1), (2, 2), (2, 2), (2, 2), (2, 1))  # encoder.py:255-259
+
+
+def instance_norm(x: Tensor, eps: float = 1e-3) -> Tensor:
+    """nn.InstanceNorm2d(eps=0.001, affine=False, track_running_stats=False), encoder.py:151-156.
+    Biased variance over (H, W) per (b, c); padded pixels participate."""
+    mean = x.mean(dim=(2, 3), keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=(2, 3), keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps)
+
+
+def conv_block(sd: SD, p: str, x: Tensor, stride: Tuple[int, int]) -> Tensor:
+    """ConvBlock.forward, encoder.py:159-181 (dropout = identity)."""
+    x = F.relu(F.conv2d(x, sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1))
+    x = F.relu(F.conv2d(x, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1))
+    x = instance_norm(x)
+    x = F.relu(F.conv2d(x, sd[p + "conv3.weight"], sd[p + "conv3.bias"], padding=1, stride=stride))
+    return x
+
+
+def depth_sep_conv(sd: SD, p: str, x: Tensor) -> Tensor:
+    """DepthSepConv2D.forward, encoder.py:73-84: depthwise 3x3 (groups=C, pad 1) then 1x1."""
+    c = x.shape[1]
+    x = F.conv2d(x, sd[p + "depth_conv.weight"], sd[p + "depth_conv.bias"], padding=1, groups=c)
+    return F.conv2d(x, sd[p + "point_conv.weight"], sd[p + "point_conv.bias"])
+
+
+def dsc_block(sd: SD, p: str, x: Tensor) -> Tensor:
+    """DSCBlock.forward, encoder.py:218-238 (no ReLU after conv3; all strides (1,1) :264-267)."""
+    x = F.relu(depth_sep_conv(sd, p + "conv1.", x))
+    x = F.relu(depth_sep_conv(sd, p + "conv2.", x))
+    x = instance_norm(x)
+    return depth_sep_conv(sd, p + "conv3.", x)
+
+
+def encoder(sd: SD, p: str, x: Tensor) -> Tensor:
+    """Encoder.forward, encoder.py:271-291. x [B,1,H,W] -> [B,C,ceil(H/16),ceil(W/8)]."""
+    for i, s in enumerate(CONV_STRIDES):
+        x = conv_block(sd, f"{p}conv_blocks.{i}.", x, s)
+    for i in range(4):
+        xt = dsc_block(sd, f"{p}dscblocks.{i}.", x)
+        x = x + xt if x.shape == xt.shape else xt  # encoder.py:289
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# Positional encodings
+# --------------------------------------------------------------------------------------
+
+
+def pe2d_table(num_channels: int, max_h: int, max_w: int) -> Tensor:
+    """PositionalEncoding2D buffer, model.py:33-43. Returns [1,C,max_h,max_w]."""
+    half = num_channels // 2
+    den = torch.pow(10000, torch.arange(0, half, 2) / num_channels)
+    pos_h = torch.arange(max_h).unsqueeze(1)
+    pos_w = torch.arange(max_w).unsqueeze(1)
+    pe = torch.zeros(max_h, max_w, num_channels)
+    pe[:, :, 0:half:2] = torch.sin(pos_w / den).unsqueeze(0)
+    pe[:, :, 1:half:2] = torch.cos(pos_w / den).unsqueeze(0)
+    pe[:, :, half::2] = torch.sin(pos_h / den).unsqueeze(1)
+    pe[:, :, half + 1 :: 2] = torch.cos(pos_h / den).unsqueeze(1)
+    return pe.permute(2, 0, 1).unsqueeze(0).contiguous()
+
+
+def pe1d_table(max_len: int, emb_dim: int) -> Tensor:
+    """PositionalEncoding1D buffer, decoder.py:21-27. Returns [1,max_len,emb_dim]."""
+    pos = torch.arange(max_len).unsqueeze(1)
+    den = torch.pow(10000, torch.arange(0, emb_dim, 2) / emb_dim)
+    pe = torch.zeros(1, max_len, emb_dim)
+    pe[0, :, 0::2] = torch.sin(pos / den)
+    pe[0, :, 1::2] = torch.cos(pos / den)
+    return pe
+
+
+def encode_to_memory(sd: SD, enc_prefix: str, pe: Tensor, x: Tensor) -> Tensor:
+    """encoder -> +PE2D -> flatten(2).permute(0,2,1), model.py:143-147. -> [B,S,C]."""
+    f = encoder(sd, enc_prefix, x)
+    f = f + pe[:, :, : f.shape[2], : f.shape[3]]
+    return f.flatten(2).permute(0, 2, 1).contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# Multi-head attention, written out (torch nn/functional.py multi_head_attention_forward)
+# --------------------------------------------------------------------------------------
+
+
+def mha(
+    q_in: Tensor,
+    kv_in: Tensor,
+    in_w: Tensor,
+    in_b: Tensor,
+    out_w: Tensor,
+    out_b: Tensor,
+    nhead: int,
+    score_bias: Optional[Tensor] = None,
+) -> Tensor:
+    """softmax(Q K^T / sqrt(hd) + bias) V with packed in_proj (rows [0:d]=Wq,[d:2d]=Wk,[2d:3d]=Wv),
+    heads = contiguous hd-wide channel slices, then out_proj (SURVEY.md Appendix A "MHA math").
+    ``score_bias`` broadcasts to [B, nhead, T, S]; float values are ADDED (so a 0/1 float
+    padding mask adds +1.0 -- reference quirk 1), -inf entries mask."""
+    b, t, d = q_in.shape
+    s = kv_in.shape[1]
+    hd = d // nhead
+    q = F.linear(q_in, in_w[:d], in_b[:d]).view(b, t, nhead, hd).transpose(1, 2)
+    k = F.linear(kv_in, in_w[d : 2 * d], in_b[d : 2 * d]).view(b, s, nhead, hd).transpose(1, 2)
+    v = F.linear(kv_in, in_w[2 * d :], in_b[2 * d :]).view(b, s, nhead, hd).transpose(1, 2)
+    scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)
+    if score_bias is not None:
+        scores = scores + score_bias
+    p = torch.softmax(scores, dim=-1)
+    o = torch.matmul(p, v).transpose(1, 2).reshape(b, t, d)
+    return F.linear(o, out_w, out_b)
+
+
+# --------------------------------------------------------------------------------------
+# Decoder  (src/transformer/decoder.py)
+# --------------------------------------------------------------------------------------
+
+
+def tgt_attn_mask(t: int, window: int) -> Tensor:
+    """get_tgt_masks / create_variable_window_mask, decoder.py:191-254: additive [T,T] mask,
+    0 on visible keys, -inf elsewhere.  window>0 and window<T: row i sees [max(0,i-window), i]
+    (window+1 keys); otherwise plain causal."""
+    i = torch.arange(t).unsqueeze(1)
+    j = torch.arange(t).unsqueeze(0)
+    visible = j <= i
+    if window > 0 and window < t:
+        visible = visible & (j >= i - window)
+    m = torch.full((t, t), float("-inf"))
+    m[visible] = 0.0
+    return m
+
+
+def memory_key_bias(memory: Tensor, memory_len) -> Optional[Tensor]:
+    """get_memory_key_padding_mask, decoder.py:150-189, expressed as an additive [B,S] bias:
+    None -> None; bool [B,S] -> 0 / -inf (torch _canonical_mask); int lengths -> float 0/1
+    that torch ADDS to the scores (+1.0 on padded keys, quirk 1)."""
+    if memory_len is None:
+        return None
+    b, s = memory.shape[:2]
+    if memory_len.dtype == torch.bool:
+        bias = torch.zeros(b, s)
+        bias[memory_len] = float("-inf")
+        return bias
+    bias = torch.zeros(b, s)
+    for i, l in enumerate(memory_len.tolist()):
+        bias[i, int(l) :] = 1.0
+    return bias
+
+
+def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def decoder_layer(sd: SD, p: str, x: Tensor, memory: Tensor, self_bias: Tensor, mem_bias: Optional[Tensor], nhead: int) -> Tensor:
+    """Post-norm nn.TransformerDecoderLayer (relu, batch_first) as configured at decoder.py:86-95;
+    math per torch nn/modules/transformer.py:1129-1199."""
+    sa = mha(x, x, sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"],
+             sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"], nhead, self_bias)
+    x = layer_norm(x + sa, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+    ca = mha(x, memory, sd[p + "multihead_attn.in_proj_weight"], sd[p + "multihead_attn.in_proj_bias"],
+             sd[p + "multihead_attn.out_proj.weight"], sd[p + "multihead_attn.out_proj.bias"], nhead, mem_bias)
+    x = layer_norm(x + ca, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+    ff = F.linear(F.relu(F.linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"])),
+                  sd[p + "linear2.weight"], sd[p + "linear2.bias"])
+    return layer_norm(x + ff, sd[p + "norm3.weight"], sd[p + "norm3.bias"])
+
+
+def decoder(sd: SD, p: str, tgt: Tensor, memory: Tensor, memory_len, cfg: OracleCfg) -> Tensor:
+    """Decoder.forward, decoder.py:104-148 -> logits [B, V, T]."""
+    b, t = tgt.shape
+    emb = sd[p + "embedding.weight"][tgt]  # row pad_idx is zero (nn.Embedding padding_idx)
+    x = emb + pe1d_table(t, cfg.d_model)  # decoder.py:124 (no sqrt(d) scaling)
+    mem_bias = memory_key_bias(memory, memory_len)
+    self_bias = tgt_attn_mask(t, cfg.attn_window).view(1, 1, t, t)
+    if mem_bias is not None:
+        # tgt_key_padding_mask = (tgt == 0).float() is ADDED (+1.0); dropped at inference
+        # (decoder.py:131-132, 253).
+        self_bias = self_bias + (tgt == cfg.pad_idx).to(torch.float32).view(b, 1, 1, t)
+        mem_bias = mem_bias.view(b, 1, 1, -1)
+    for i in range(cfg.num_layers):
+        x = decoder_layer(sd, f"{p}transformer_decoder.layers.{i}.", x, memory, self_bias, mem_bias, cfg.nhead)
+    w = sd[p + "out_layer.weight"][:, :, 0]  # Conv1d k=1 head, decoder.py:98-102,145-146
+    return (F.linear(x, w, sd[p + "out_layer.bias"])).permute(0, 2, 1).contiguous()
+
+
+def ce_loss(logits_bvt: Tensor, target: Tensor, pad_idx: int = 0) -> Tensor:
+    """CrossEntropyLoss(ignore_index=pad) over class dim 1 of [B,V,T], model.py:109,166."""
+    logp = torch.log_softmax(logits_bvt, dim=1)
+    picked = -logp.gather(1, target.unsqueeze(1)).squeeze(1)
+    keep = target != pad_idx
+    return (picked * keep).sum() / keep.sum()
+
+
+# --------------------------------------------------------------------------------------
+# Unimodal Transformer  (src/transformer/model.py:54-262)
+# --------------------------------------------------------------------------------------
+
+
+def transformer_forward(sd: SD, x: Tensor, xl, y_in: Tensor, cfg: OracleCfg, max_h: int, max_w: int) -> Tensor:
+    """Transformer.forward, model.py:141-150."""
+    pe = pe2d_table(cfg.d_model, math.ceil(max_h / HEIGHT_REDUCTION), math.ceil(max_w / WIDTH_REDUCTION))
+    mem = encode_to_memory(sd, "encoder.", pe, x)
+    return decoder(sd, "decoder.", y_in, mem, xl, cfg)
+
+
+def greedy_decode(sd: SD, dec_prefix: str, memory: Tensor, sos: int, eos: int, max_len: int, cfg: OracleCfg,
+                  return_logits: bool = False):
+    """validation_step loop, model.py:182-193: bs=1, memory_len=None, full re-run per step,
+    argmax of logits[0,:,-1]; stops after emitting eos.  With return_logits the per-step
+    (top1, top2) logit values are returned too (get_pred_seq_and_pred_prob_seq, model.py:250-260)."""
+    assert memory.shape[0] == 1
+    y_in = torch.tensor([[sos]], dtype=torch.long)
+    toks: List[int] = []
+    tops: List[Tuple[float, float]] = []
+    for _ in range(max_len):
+        logits = decoder(sd, dec_prefix, y_in, memory, None, cfg)[0, :, -1]
+        top2 = logits.topk(2)
+        tok = int(logits.argmax())
+        toks.append(tok)
+        tops.append((float(top2.values[0]), float(top2.values[1])))
+        if tok == eos:
+            break
+        y_in = torch.cat([y_in, torch.tensor([[tok]])], dim=1)
+    return (toks, tops) if return_logits else toks
+
+
+# --------------------------------------------------------------------------------------
+# Multimodal  (src/transformer/model.py:268-726)
+# --------------------------------------------------------------------------------------
+
+
+def cross_attention(sd: SD, p: str, query: Tensor, len_query, key_value: Tensor, len_kv, nhead: int = 4) -> Tensor:
+    """CrossAttention.forward, model.py:299-355.  The bool mask [B,La,Lb] with block
+    [lq:, lkv:] = True is tiled with .repeat(nhead,1,1) (model.py:354), so batched head index
+    b*nhead+h receives the mask of sample (b*nhead+h) % B  (reference quirk 2)."""
+    b, la, _ = query.shape
+    lb = key_value.shape[1]
+    bias = None
+    if len_query is not None and len_kv is not None:
+        m = torch.zeros(b, la, lb)
+        for i, (lq, lkv) in enumerate(zip(len_query.tolist(), len_kv.tolist())):
+            m[i, int(lq) :, int(lkv) :] = float("-inf")
+        idx = (torch.arange(b * nhead)) % b
+        bias = m[idx].view(b, nhead, la, lb)
+    a = p + "attention."
+    return mha(query, key_value, sd[a + "in_proj_weight"], sd[a + "in_proj_bias"],
+               sd[a + "out_proj.weight"], sd[a + "out_proj.bias"], nhead, bias)
+
+
+def _len_mask(n: int, lens) -> Tensor:
+    m = torch.zeros(len(lens), n, dtype=torch.bool)
+    for i, l in enumerate(lens.tolist()):
+        m[i, int(l) :] = True
+    return m
+
+
+def mixer(sd: SD, kind: str, xi: Tensor, xa: Tensor, xli, xla):
+    """mixer_concat / mixer_attn_img / mixer_attn_audio / mixer_attn_both, model.py:644-726."""
+    have = xli is not None and xla is not None
+    if kind == "concat":
+        x = torch.cat([xi, xa], dim=1)
+        xl = torch.cat([_len_mask(xi.shape[1], xli), _len_mask(xa.shape[1], xla)], dim=1) if have else None
+        return x, xl  # bool mask -> true -inf masking (model.py:663-672)
+    if kind == "attn_img":  # q = audio, kv = image
+        return cross_attention(sd, "cross_attn.", xa, xla, xi, xli), (xla if have else None)
+    if kind == "attn_audio":  # q = image, kv = audio
+        return cross_attention(sd, "cross_attn.", xi, xli, xa, xla), (xli if have else None)
+    if kind == "attn_both":
+        # model.py:723-725: variable shadowing -- the second attention uses the ALREADY
+        # ATTENDED audio as key/value (quirk 3); one shared cross_attn module.
+        xa2, xla2 = mixer(sd, "attn_img", xi, xa, xli, xla)
+        xi2, xli2 = mixer(sd, "attn_audio", xi, xa2, xli, xla2)
+        return mixer(sd, "concat", xi2, xa2, xli2, xla2)
+    raise ValueError(f"Invalid mixer type: {kind}")
+
+
+def multimodal_forward(sd: SD, xi: Tensor, xli, xa: Tensor, xla, y_in: Tensor, cfg: OracleCfg, mixer_type: str,
+                       max_img_hw: Tuple[int, int], max_audio_hw: Tuple[int, int], modality: str = "both") -> Tensor:
+    """MultimodalTransformer.forward / encoder_forward, model.py:485-543 with the modality
+    choice of apply_teacher_forcing_modality (model.py:561-575) passed in explicitly."""
+    pe_i = pe2d_table(cfg.d_model, math.ceil(max_img_hw[0] / 16), math.ceil(max_img_hw[1] / 8))
+    pe_a = pe2d_table(cfg.d_model, math.ceil(max_audio_hw[0] / 16), math.ceil(max_audio_hw[1] / 8))
+    mi = encode_to_memory(sd, "image_encoder.", pe_i, xi)
+    ma = encode_to_memory(sd, "audio_encoder.", pe_a, xa)
+    if modality == "image":
+        mem, ml = mi, xli
+    elif modality == "audio":
+        mem, ml = ma, xla
+    else:
+        mem, ml = mixer(sd, mixer_type, mi, ma, xli, xla)
+    return decoder(sd, "decoder.", y_in, mem, ml, cfg)
+
+
+# --------------------------------------------------------------------------------------
+# Optimiser and metrics
+# --------------------------------------------------------------------------------------
+
+
+def adam_step(params: Sequence[Tensor], grads: Sequence[Tensor], exp_avg: Sequence[Tensor], exp_avg_sq: Sequence[Tensor],
+              step: int, lr: float = 1e-4, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
+    """torch.optim.Adam single-tensor math (torch optim/adam.py:347), as configured at
+    model.py:134-139 (no weight decay, no amsgrad).  ``step`` is 1-based.  In place."""
+    bc1 = 1.0 - b1**step
+    bc2 = 1.0 - b2**step
+    for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+def levenshtein(a: Sequence, b: Sequence) -> int:
+    """metrics.py:56-74."""
+    if len(a) > len(b):
+        a, b = b, a
+    prev = list(range(len(a) + 1))
+    for i in range(1, len(b) + 1):
+        cur = [i] + [0] * len(a)
+        for j in range(1, len(a) + 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (a[j - 1] != b[i - 1]))
+        prev = cur
+    return prev[len(a)]
+
+
+def compute_ed_metrics(y_true: List[List[str]], y_pred: List[List[str]]) -> Dict[str, float]:
+    """compute_ed_metrics, metrics.py:52-88."""
+    ed_acc = length_acc = label_acc = 0
+    for t, h in zip(y_true, y_pred):
+        ed = levenshtein(t, h)
+        ed_acc += ed
+        length_acc += len(t)
+        label_acc += ed > 0
+    return {"sym-er": 100.0 * ed_acc / length_acc, "seq-er": 100.0 * label_acc / len(y_pred)}
+
+
+# --------------------------------------------------------------------------------------
+# Collate contract (src/data/preprocessing.py:55-144)
+# --------------------------------------------------------------------------------------
+
+
+def collate_unimodal(batch, pad_value: float):
+    """ar_batch_preparation_unimodal, preprocessing.py:85-103: right/bottom pad x with
+    pad_value (image 1.0 :110, audio 0.0 :117), xl int32, y_in=y[:-1], y_out=y[1:] padded with 0 (int64)."""
+    xs, xls, ys = zip(*batch)
+    mh = max(t.shape[1] for t in xs)
+    mw = max(t.shape[2] for t in xs)
+    x = torch.stack([F.pad(t, (0, mw - t.shape[2], 0, mh - t.shape[1]), value=pad_value) for t in xs]).float()
+    xl = torch.tensor(xls, dtype=torch.int32)
+    ml = max(len(t) for t in ys) - 1
+    y_in = torch.stack([F.pad(t[:-1], (0, ml - (len(t) - 1))) for t in ys]).long()
+    y_out = torch.stack([F.pad(t[1:], (0, ml - (len(t) - 1))) for t in ys]).long()
+    return x, xl, y_in, y_out
