@@ -1,0 +1,112 @@
+/* libomr_hip.so -- C ABI of the MI355X (gfx950) encoder/decoder hot path.
+ *
+ * The reference (mariaalfaroc/omr_a2s_multimodal_transformer) has no FFI: its hot path is the set of ATen ops that
+ * src/transformer/{encoder,decoder,model}.py reach through torch.nn.  Each entry point below
+ * replaces one of those op families; the reference call site it stands in for is cited per function.
+ *
+ * Conventions: every function returns 0 (OMR_OK) or a negative error code and never throws; the caller owns
+ * all buffers (device pointers); `stream` is a hipStream_t passed as void*; dtype is OMR_F32 (0) or OMR_BF16 (1)
+ * and names the activation/weight element type (accumulation is always fp32); "small vectors" (bias, LayerNorm
+ * gamma/beta, statistics) are always fp32.  Encoder activations are NHWC; token matrices are row-major [rows][ld].
+ * No hidden state: every call is re-entrant across streams.
+ */
+#ifndef OMR_HIP_H
+#define OMR_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMR_DTYPE_F32 0
+#define OMR_DTYPE_BF16 1
+
+int omr_abi_version(void);
+
+/* ---- elementwise / gather ------------------------------------------------------------------------------ */
+int omr_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
+/* residual adds: encoder.py:289 (x + xt) */
+int omr_add(int dtype, const void* a, const void* b, void* out, long n, void* stream);
+/* ReLU(+dropout) backward: dx = dy * (y > 0) * scale   (aten::threshold_backward; encoder.py:163-176) */
+int omr_relu_bwd(int dtype, const void* dy, const void* y, void* dx, long n, float scale, void* stream);
+/* nn.Dropout / nn.Dropout2d (encoder.py:98-104, decoder.py:19, model.py:31): counter-based mask, regenerated not stored.
+ * channel_mode=1: one decision per (sample, channel) of an NHWC tensor with `per_sample` = H*W*C elements per sample. */
+int omr_dropout(int dtype, const void* x, void* out, long n, float p, unsigned long long seed, int channel_mode, long per_sample, int C,
+                void* stream);
+/* nn.Embedding + PositionalEncoding1D: out[m] = table[tok[m]] + pe[m % T]   (decoder.py:124) */
+int omr_embed_pe_fwd(int dtype, const long* tokens, const void* table, const float* pe, void* out, long M, int T_len, int d, int vocab,
+                     void* stream);
+/* embedding backward: dtable[tok[m]] += dout[m], PAD row skipped (nn.Embedding padding_idx, decoder.py:73-77) */
+int omr_embed_bwd(int dtype, const long* tokens, const void* dout, float* dtable, long M, int d, int pad_idx, int vocab, void* stream);
+/* PositionalEncoding2D on NHWC maps: out[b,i,j,c] = x[b,i,j,c] + pe[i,j,c], pe laid out [maxh][maxw][C]   (model.py:45-47) */
+int omr_add_pe2d(int dtype, const void* x, const float* pe_hwc, void* out, int B, int h, int w, int C, int maxh, int maxw, void* stream);
+/* bias gradients: db[n] += sum_m dy[m][n] */
+int omr_colsum(int dtype, const void* dy, float* db, long M, int N, long ld, void* stream);
+/* torch.optim.Adam step over one flat fp32 buffer (model.py:134-139; torch optim/adam.py:347); step is 1-based.
+ * p_bf16 (nullable) receives the bf16 compute copy of the updated parameters in the same pass. */
+int omr_adam(float* p, const float* g, float* m, float* v, void* p_bf16, long n, int step, float lr, float b1, float b2, float eps,
+             float grad_scale, void* stream);
+/* greedy token pick: argmax(dim=-1) / topk(1) of the last-step logits (model.py:187,253) */
+int omr_argmax(const float* x, int n, long* idx_out, float* val_out, void* stream);
+
+/* ---- normalisation ------------------------------------------------------------------------------------- */
+long omr_instnorm_workspace_bytes(int B, int C);
+/* nn.InstanceNorm2d(eps=1e-3, affine=False) statistics on x[B][HW][C] (encoder.py:151-156,174,232); the apply is
+ * fused into the consumer conv (in_mean / in_rstd arguments below). */
+int omr_instnorm_stats(int dtype, const void* x, float* mean, float* rstd, int B, long HW, int C, float eps, void* workspace, void* stream);
+int omr_instnorm_bwd(int dtype, const void* dxhat, const void* x, const float* mean, const float* rstd, void* dx, int B, long HW, int C,
+                     int relu_mask, float relu_scale, void* workspace, void* stream);
+/* post-norm residual: out = LayerNorm(x + res) (eps 1e-5), torch nn/modules/transformer.py:1146-1154 */
+int omr_add_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* out, float* mean,
+                          float* rstd, long M, int d, float eps, void* stream);
+int omr_add_layernorm_bwd(int dtype, const void* dy, const void* x, const void* res, const float* gamma, const float* mean,
+                          const float* rstd, void* ds, float* dgamma, float* dbeta, long M, int d, void* stream);
+
+/* ---- GEMM: C[M,N] (+)= act(opA(A) . opB(B)^T + bias) ------------------------------------------------------ */
+/* aten::linear/addmm/mm of the decoder layers (torch nn/modules/transformer.py:1158-1199), 1x1 point_conv
+ * (encoder.py:65-70), Conv1d(k=1) head (decoder.py:98-102,146).  transA/transB: operand stored reduction-major.
+ * split_k > 1 accumulates into fp32 C with atomics (C must hold the running sum / zeros). */
+int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C,
+             long ldc, const float* bias, int relu, int accumulate, int split_k, void* stream);
+
+/* ---- convolutions (NHWC) --------------------------------------------------------------------------------- */
+/* nn.Conv2d 3x3 pad 1 (encoder.py:132-150) with fused bias + ReLU, optional fused InstanceNorm apply on the input
+ * (in_mean/in_rstd [B][CIN]) and optional epilogue mask (y = mask>0 ? y*mask_scale : 0).  Weights [COUT][3][3][CIN].
+ * dil_* > 1 reads the input as if zero-dilated: with flipped weights (omr_conv3x3_weight_flip) this is the data
+ * gradient of a strided conv.  CIN == 1 takes the direct (non-MFMA) first-layer path. */
+int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const float* bias, void* y, const float* in_mean, const float* in_rstd,
+                    const void* out_mask, float mask_scale, int B, int H, int W, int CIN, int COUT, int stride_h, int stride_w, int dil_h,
+                    int dil_w, int Ho, int Wo, int relu, void* stream);
+int omr_conv3x3_weight_flip(int dtype, const void* w, void* wd, int COUT, int CIN, void* stream);
+/* dw[COUT][3][3][CIN] (fp32) += dy^T * im2col(x) */
+int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, const float* in_mean, const float* in_rstd, int B, int H, int W,
+                      int CIN, int COUT, int stride_h, int stride_w, int Ho, int Wo, void* stream);
+/* depthwise 3x3, stride 1, pad 1 (DepthSepConv2D.depth_conv, encoder.py:56-64); flip=1 mirrors the taps (data gradient) */
+int omr_dwconv3x3(int dtype, const void* x, const void* w, const float* bias, void* y, const float* in_mean, const float* in_rstd,
+                  const void* out_mask, float mask_scale, int B, int H, int W, int C, int flip, void* stream);
+int omr_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, const float* in_mean, const float* in_rstd, int B,
+                        int H, int W, int C, void* stream);
+
+/* ---- attention ------------------------------------------------------------------------------------------ */
+/* softmax(Q K^T / sqrt(hd) + masks) V per head (torch nn/functional.py multi_head_attention_forward; decoder.py:86-95,
+ * model.py:292-297,323).  q/k/v/o are [B][rows][ld*] with head h at columns [h*hd, (h+1)*hd).  key_bias [B][S] is
+ * ADDED (float +1.0 padding masks, -inf for bool masks); causal/window per decoder.py:191-217; blk_lq/blk_lkv [B]
+ * reproduce CrossAttention.create_attention_mask incl. its (b*H+h)%B tiling (model.py:343-354). */
+int omr_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
+                 long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
+                 const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed, void* stream);
+int omr_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta_ws,
+                 void* dq, void* dk, void* dv, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, long bsq,
+                 long bsk, long bsv, long bso, long bsdo, long bsdq, long bsdk, long bsdv, int B, int H, int T, int S, int head_dim,
+                 int causal, int window, const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p,
+                 unsigned long long seed, void* stream);
+
+/* ---- loss ------------------------------------------------------------------------------------------------ */
+/* CrossEntropyLoss(ignore_index=pad) (model.py:109,166) on row-major logits [M][ldv]; acc2 = {sum, count} (fp64). */
+int omr_ce_fwd(int dtype, const void* logits, const long* target, float* lse, double* acc2, float* loss_out, long M, int V, long ldv,
+               int pad_idx, void* stream);
+int omr_ce_bwd(int dtype, const void* logits, const long* target, const float* lse, const double* acc2, void* dlogits, long M, int V,
+               long ldv, int pad_idx, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

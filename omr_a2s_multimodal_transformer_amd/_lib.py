@@ -1,0 +1,104 @@
+"""ctypes binding of libomr_hip.so (the C ABI declared in include/omr_hip.h).
+
+The prototypes are parsed from the header itself, so the header stays the single source of truth.
+There is NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+HEADER = os.path.join(REPO_ROOT, "include", "omr_hip.h")
+LIB_PATH = os.path.join(_HERE, "libomr_hip.so")
+
+F32, BF16 = 0, 1
+_DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
+
+_ERRORS = {-1: "invalid argument", -2: "kernel launch failed", -3: "unsupported configuration"}
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DTYPE_CODE[dt]
+    except KeyError:
+        raise TypeError(f"libomr_hip supports float32 and bfloat16, got {dt}") from None
+
+
+def parse_header(path: str = HEADER) -> Dict[str, Tuple[str, List[str]]]:
+    """{function name: (return type, [argument C types])} for every prototype in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    protos: Dict[str, Tuple[str, List[str]]] = {}
+    for m in re.finditer(r"\b(int|long)\s+(omr_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        types: List[str] = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                types.append(a if "*" in a else a.rsplit(" ", 1)[0])
+        protos[name] = (ret, types)
+    return protos
+
+
+def _ctype(t: str):
+    if "*" in t:
+        return ctypes.c_void_p
+    return {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
+            "unsigned long long": ctypes.c_ulonglong}[t]
+
+
+class _Lib:
+    def __init__(self) -> None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        for name, (ret, types) in self.protos.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = ctypes.c_long if ret == "long" else ctypes.c_int
+            fn.argtypes = [_ctype(t) for t in types]
+
+    def call(self, name: str, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            raise RuntimeError(f"libomr_hip: {name} failed: {_ERRORS.get(rc, rc)}")
+
+    def query(self, name: str, *args) -> int:
+        return int(getattr(self.cdll, name)(*args))
+
+
+_LIB = None
+
+
+def lib() -> _Lib:
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib()
+    return _LIB
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be contiguous in the layout the kernel expects."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def cur_stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("omr_a2s_multimodal_transformer_amd ops run on the GPU only (HIP kernels); got a CPU tensor. "
+                               "There is no CPU fallback.")

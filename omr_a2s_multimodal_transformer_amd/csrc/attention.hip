@@ -1,0 +1,495 @@
+// Fused multi-head attention (flash style: scores never leave the chip) for gfx950.
+// Reference math: torch nn/functional.py multi_head_attention_forward as used by
+//   nn.TransformerDecoderLayer self/cross attention (decoder.py:86-95) and CrossAttention (model.py:289-355):
+//   P = softmax(Q K^T / sqrt(hd) + bias), O = dropout(P) V, heads = contiguous hd-wide channel slices.
+// Mask semantics reproduced exactly:
+//   * key_bias[b][key]  : ADDED to the score.  Float padding masks add +1.0 (quirk 1); bool masks arrive as -inf.
+//   * causal / window   : key <= q, and key >= q - window when 0 < window < T (decoder.py:191-217).
+//   * block mask        : score = -inf where q >= lq[b'] and key >= lkv[b'] with b' = (b*H + h) % B (quirk 2, model.py:349-354).
+//
+// Data flow per wave (32 query rows), keys on the MFMA M dimension so that each LANE owns one query row:
+//   S^T = K . Q^T        (A = K tile from LDS, B = Q fragments held in registers)      -> softmax is lane-local
+//   O^T += V^T . P^T     (A = V^T tile from LDS, B = P^T straight from the accumulator registers, permuted-k order)
+// Backward: dQ kernel (same orientation) and dK/dV kernel (queries on the register axis, keys on the lanes).
+#include "omr_common.h"
+#include "omr_hip.h"
+
+namespace {
+
+struct AttnArgs {
+    const void* q; const void* k; const void* v; void* o;
+    long ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;      // row / batch strides in elements
+    float* lse;                                        // [B][H][T]
+    const float* key_bias;                             // [B][S] or null
+    const int* blk_lq; const int* blk_lkv;             // [B] or null
+    int B, H, T, S; float scale; int causal; int window;
+    uint32_t drop_thresh; float drop_scale; uint64_t seed;
+    // backward only
+    const void* dout; long lddo, bsdo;
+    const float* delta;                                // [B][H][T]
+    void* dq; void* dk; void* dv; long lddq, lddk, lddv, bsdq, bsdk, bsdv;
+};
+
+template <typename T> struct ACfg {
+    static constexpr int VEC = Frag<T>::N;
+    static constexpr int NFR = 16 / VEC;   // operand fragments per 32-wide accumulator block (2 bf16 / 4 fp32)
+};
+
+// Fragment of a k-contiguous LDS row whose k order matches accumulator registers s*VEC .. s*VEC+VEC-1 of a
+// 32-row block: element j  <->  k = kb + acc_row(s*VEC + j, lane).
+template <typename T> __device__ __forceinline__ typename Frag<T>::type load_kperm_frag(const T* row, int kb, int s, int h);
+template <> __device__ __forceinline__ bf16x8 load_kperm_frag<bf16>(const bf16* row, int kb, int s, int h) {
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row + kb + 16 * s + 4 * h);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + kb + 16 * s + 4 * h + 8);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+template <> __device__ __forceinline__ f32x4 load_kperm_frag<float>(const float* row, int kb, int s, int h) {
+    return *reinterpret_cast<const f32x4*>(row + kb + 8 * s + 4 * h);
+}
+
+template <typename T> __device__ __forceinline__ typename Frag<T>::type acc_to_frag(const f32x16& acc, int s) {
+    typename Frag<T>::type f;
+#pragma unroll
+    for (int j = 0; j < Frag<T>::N; ++j) f[j] = from_f32<T>(acc[s * Frag<T>::N + j]);
+    return f;
+}
+
+// Stage rows [r0, r0+NR) x HD of a [rows][ld] matrix into LDS row-major (pitch P), zero beyond nrows.
+template <typename T, int HD, int NR, int P>
+__device__ __forceinline__ void stage_rows(T* lds, const T* src, long ld, int r0, int nrows, int tid) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N, CPR = HD / VEC;
+    for (int c = tid; c < NR * CPR; c += 256) {
+        const int r = c / CPR, kc = (c % CPR) * VEC;
+        F v = frag_zero<T>();
+        if (r0 + r < nrows) v = *reinterpret_cast<const F*>(src + (long)(r0 + r) * ld + kc);
+        *reinterpret_cast<F*>(lds + r * P + kc) = v;
+    }
+}
+// Same tile transposed: lds[d][r] (pitch P over r).
+template <typename T, int HD, int NR, int P>
+__device__ __forceinline__ void stage_rows_t(T* lds, const T* src, long ld, int r0, int nrows, int tid) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N, CPR = HD / VEC;
+    for (int c = tid; c < NR * CPR; c += 256) {
+        const int r = c / CPR, kc = (c % CPR) * VEC;
+        F v = frag_zero<T>();
+        if (r0 + r < nrows) v = *reinterpret_cast<const F*>(src + (long)(r0 + r) * ld + kc);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) lds[(kc + e) * P + r] = v[e];
+    }
+}
+
+__device__ __forceinline__ bool attn_visible(const AttnArgs& a, int q, int key, int lq, int lkv) {
+    if (key >= a.S || q >= a.T) return false;
+    if (a.causal) {
+        if (key > q) return false;
+        if (a.window > 0 && a.window < a.T && key < q - a.window) return false;
+    }
+    if (lq >= 0 && q >= lq && key >= lkv) return false;
+    return true;
+}
+__device__ __forceinline__ float attn_keep(const AttnArgs& a, int b, int h, int q, int key) {
+    if (a.drop_thresh == 0) return 1.f;
+    const uint64_t idx = (((uint64_t)b * a.H + h) * a.T + q) * (uint64_t)a.S + key;
+    return drop_keep(a.seed, idx, a.drop_thresh) ? a.drop_scale : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward.  grid = (ceil(T/128), H, B); wave w owns query rows q0 + 32w .. +31; KV tiles of 64 keys.
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = ACfg<T>::VEC, NFR = ACfg<T>::NFR, KS = KStep<T>::value;
+    constexpr int NKS = HD / KS, NDB = HD / 32, BKV = 64;
+    constexpr int PK = HD + VEC;          // Ks pitch
+    constexpr int PV = BKV + 4;   // Vt pitch: 136 B (bf16) / 272 B (fp32) -> conflict-free permuted reads
+    __shared__ __attribute__((aligned(16))) T Ks[BKV * PK];
+    __shared__ __attribute__((aligned(16))) T Vt[HD * PV];
+    __shared__ float bias_s[BKV];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int q = q0 + wave * 32 + (lane & 31);
+    const T* Q = (const T*)a.q + (long)b * a.bsq + h * HD;
+    const T* K = (const T*)a.k + (long)b * a.bsk + h * HD;
+    const T* V = (const T*)a.v + (long)b * a.bsv + h * HD;
+
+    F qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+        qf[ks] = q < a.T ? *reinterpret_cast<const F*>(Q + (long)q * a.ldq + ks * KS + hh * VEC) : frag_zero<T>();
+    int lq = -1, lkv = 0;
+    if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
+
+    f32x16 acc_o[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    int kv_beg = 0, kv_end = a.S;
+    if (a.causal) {
+        kv_end = min(a.S, q0 + 128);
+        if (a.window > 0 && a.window < a.T) kv_beg = max(0, q0 - a.window) / BKV * BKV;
+    }
+    for (int kv0 = kv_beg; kv0 < kv_end; kv0 += BKV) {
+        __syncthreads();
+        stage_rows<T, HD, BKV, PK>(Ks, K, a.ldk, kv0, a.S, tid);
+        stage_rows_t<T, HD, BKV, PV>(Vt, V, a.ldv, kv0, a.S, tid);
+        if (tid < BKV) bias_s[tid] = (a.key_bias && kv0 + tid < a.S) ? a.key_bias[(long)b * a.S + kv0 + tid] : 0.f;
+        __syncthreads();
+
+        f32x16 st[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[mb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const F kf = *reinterpret_cast<const F*>(&Ks[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
+                mma32(st[mb], kf, qf[ks]);
+            }
+        }
+        // scores -> masked, running max
+        float mx = -INFINITY;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = mb * 32 + acc_row(r, lane);
+                const int key = kv0 + kl;
+                float s = st[mb][r] * a.scale + bias_s[kl];
+                if (!attn_visible(a, q, key, lq, lkv)) s = -INFINITY;
+                st[mb][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(st[mb][r] - m_use);   // exp(-inf) = 0 for masked keys
+                psum += p;
+                st[mb][r] = (a.drop_thresh == 0) ? p : p * attn_keep(a, b, h, q, kv0 + mb * 32 + acc_row(r, lane));
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+        // O^T += V^T . P^T
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int s = 0; s < NFR; ++s) {
+                const F pf = acc_to_frag<T>(st[mb], s);
+#pragma unroll
+                for (int d = 0; d < NDB; ++d) {
+                    const F vf = load_kperm_frag<T>(&Vt[(d * 32 + (lane & 31)) * PV], mb * 32, s, hh);
+                    mma32(acc_o[d], vf, pf);
+                }
+            }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (q < a.T) {
+        T* O = (T*)a.o + (long)b * a.bso + (long)q * a.ldo + h * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[d * 32 + acc_row(r, lane)] = from_f32<T>(acc_o[d][r] * inv);
+        if (hh == 0 && a.lse) a.lse[((long)b * a.H + h) * a.T + q] = (l_tot > 0.f) ? m_run + logf(l_tot) : -INFINITY;
+    }
+}
+
+// delta[b][h][q] = sum_d dO[q][h*HD+d] * O[q][h*HD+d]
+template <typename T, int HD>
+__global__ void attn_delta_kernel(AttnArgs a) {
+    const long n = (long)a.B * a.H * a.T;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % a.T); const long bh = i / a.T; const int h = (int)(bh % a.H); const long b = bh / a.H;
+        const T* o = (const T*)a.o + b * a.bso + (long)q * a.ldo + h * HD;
+        const T* g = (const T*)a.dout + b * a.bsdo + (long)q * a.lddo + h * HD;
+        float s = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < HD; ++d) s += to_f32(o[d]) * to_f32(g[d]);
+        ((float*)a.delta)[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward, dQ.  Same orientation as the forward: lane = query row.
+//   S^T = K Q^T ; P^T = exp(S^T - lse) ; dP^T = V dO^T ; dS^T = P^T o (M o dP^T - delta) ; dQ^T += K^T dS^T
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = ACfg<T>::VEC, NFR = ACfg<T>::NFR, KS = KStep<T>::value;
+    constexpr int NKS = HD / KS, NDB = HD / 32, BKV = 64;
+    constexpr int PK = HD + VEC;
+    constexpr int PV = BKV + 4;
+    __shared__ __attribute__((aligned(16))) T Ks[BKV * PK];
+    __shared__ __attribute__((aligned(16))) T Vs[BKV * PK];
+    __shared__ __attribute__((aligned(16))) T Kt[HD * PV];
+    __shared__ float bias_s[BKV];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int q = q0 + wave * 32 + (lane & 31);
+    const T* Q = (const T*)a.q + (long)b * a.bsq + h * HD;
+    const T* K = (const T*)a.k + (long)b * a.bsk + h * HD;
+    const T* V = (const T*)a.v + (long)b * a.bsv + h * HD;
+    const T* DO = (const T*)a.dout + (long)b * a.bsdo + h * HD;
+
+    F qf[NKS], dof[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        qf[ks] = q < a.T ? *reinterpret_cast<const F*>(Q + (long)q * a.ldq + ks * KS + hh * VEC) : frag_zero<T>();
+        dof[ks] = q < a.T ? *reinterpret_cast<const F*>(DO + (long)q * a.lddo + ks * KS + hh * VEC) : frag_zero<T>();
+    }
+    const long sidx = ((long)b * a.H + h) * a.T + q;
+    const float lse = q < a.T ? a.lse[sidx] : 0.f;
+    const float dl = q < a.T ? a.delta[sidx] : 0.f;
+    int lq = -1, lkv = 0;
+    if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
+
+    f32x16 acc_q[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_q[d][r] = 0.f;
+
+    int kv_beg = 0, kv_end = a.S;
+    if (a.causal) {
+        kv_end = min(a.S, q0 + 128);
+        if (a.window > 0 && a.window < a.T) kv_beg = max(0, q0 - a.window) / BKV * BKV;
+    }
+    for (int kv0 = kv_beg; kv0 < kv_end; kv0 += BKV) {
+        __syncthreads();
+        stage_rows<T, HD, BKV, PK>(Ks, K, a.ldk, kv0, a.S, tid);
+        stage_rows<T, HD, BKV, PK>(Vs, V, a.ldv, kv0, a.S, tid);
+        stage_rows_t<T, HD, BKV, PV>(Kt, K, a.ldk, kv0, a.S, tid);
+        if (tid < BKV) bias_s[tid] = (a.key_bias && kv0 + tid < a.S) ? a.key_bias[(long)b * a.S + kv0 + tid] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            f32x16 st, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const F kf = *reinterpret_cast<const F*>(&Ks[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
+                mma32(st, kf, qf[ks]);
+                const F vf = *reinterpret_cast<const F*>(&Vs[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
+                mma32(dp, vf, dof[ks]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = mb * 32 + acc_row(r, lane);
+                const int key = kv0 + kl;
+                float p = 0.f;
+                if (attn_visible(a, q, key, lq, lkv)) p = __expf(st[r] * a.scale + bias_s[kl] - lse);
+                const float keep = attn_keep(a, b, h, q, key);
+                st[r] = p * (dp[r] * keep - dl);     // dS^T
+            }
+#pragma unroll
+            for (int s = 0; s < NFR; ++s) {
+                const F sf = acc_to_frag<T>(st, s);
+#pragma unroll
+                for (int d = 0; d < NDB; ++d) {
+                    const F kf = load_kperm_frag<T>(&Kt[(d * 32 + (lane & 31)) * PV], mb * 32, s, hh);
+                    mma32(acc_q[d], kf, sf);
+                }
+            }
+        }
+    }
+    if (q < a.T) {
+        T* DQ = (T*)a.dq + (long)b * a.bsdq + (long)q * a.lddq + h * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) DQ[d * 32 + acc_row(r, lane)] = from_f32<T>(acc_q[d][r] * a.scale);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward, dK and dV.  grid = (ceil(S/128), H, B); wave w owns keys k0 + 32w .. +31 (lane = key), queries
+// on the register axis:  S = Q K^T ; P = exp(S - lse) ; dP = dO V^T ; dS = P o (M o dP - delta)
+//   dV += (M o P)^T dO      dK += dS^T Q        (A operand straight from accumulator registers)
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = ACfg<T>::VEC, NFR = ACfg<T>::NFR, KS = KStep<T>::value;
+    constexpr int NKS = HD / KS, NDB = HD / 32, BQ = 32;
+    constexpr int PK = HD + VEC;
+    constexpr int PT = BQ + 4;   // transposed tiles [d][q]
+    __shared__ __attribute__((aligned(16))) T Qs[BQ * PK];
+    __shared__ __attribute__((aligned(16))) T Ds[BQ * PK];
+    __shared__ __attribute__((aligned(16))) T Qt[HD * PT];
+    __shared__ __attribute__((aligned(16))) T Dt[HD * PT];
+    __shared__ __attribute__((aligned(16))) float lse_s[BQ];
+    __shared__ __attribute__((aligned(16))) float del_s[BQ];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 128;
+    const int key = k0 + wave * 32 + (lane & 31);
+    const T* Q = (const T*)a.q + (long)b * a.bsq + h * HD;
+    const T* K = (const T*)a.k + (long)b * a.bsk + h * HD;
+    const T* V = (const T*)a.v + (long)b * a.bsv + h * HD;
+    const T* DO = (const T*)a.dout + (long)b * a.bsdo + h * HD;
+
+    F kf[NKS], vf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        kf[ks] = key < a.S ? *reinterpret_cast<const F*>(K + (long)key * a.ldk + ks * KS + hh * VEC) : frag_zero<T>();
+        vf[ks] = key < a.S ? *reinterpret_cast<const F*>(V + (long)key * a.ldv + ks * KS + hh * VEC) : frag_zero<T>();
+    }
+    const float kb = (a.key_bias && key < a.S) ? a.key_bias[(long)b * a.S + key] : 0.f;
+    int lq = -1, lkv = 0;
+    if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
+
+    f32x16 acc_k[NDB], acc_v[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_k[d][r] = 0.f; acc_v[d][r] = 0.f; }
+
+    int q_beg = 0, q_end = a.T;
+    if (a.causal) {
+        q_beg = k0 / BQ * BQ;                                   // rows q < k0 never see these keys
+        if (a.window > 0 && a.window < a.T) q_end = min(a.T, k0 + 128 + a.window);
+    }
+    const long sbase = ((long)b * a.H + h) * a.T;
+    for (int q0 = q_beg; q0 < q_end; q0 += BQ) {
+        __syncthreads();
+        stage_rows<T, HD, BQ, PK>(Qs, Q, a.ldq, q0, a.T, tid);
+        stage_rows<T, HD, BQ, PK>(Ds, DO, a.lddo, q0, a.T, tid);
+        stage_rows_t<T, HD, BQ, PT>(Qt, Q, a.ldq, q0, a.T, tid);
+        stage_rows_t<T, HD, BQ, PT>(Dt, DO, a.lddo, q0, a.T, tid);
+        if (tid < BQ) {
+            lse_s[tid] = q0 + tid < a.T ? a.lse[sbase + q0 + tid] : 0.f;
+            del_s[tid] = q0 + tid < a.T ? a.delta[sbase + q0 + tid] : 0.f;
+        }
+        __syncthreads();
+        f32x16 st, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const F qf = *reinterpret_cast<const F*>(&Qs[(lane & 31) * PK + ks * KS + hh * VEC]);
+            mma32(st, qf, kf[ks]);
+            const F df = *reinterpret_cast<const F*>(&Ds[(lane & 31) * PK + ks * KS + hh * VEC]);
+            mma32(dp, df, vf[ks]);
+        }
+        f32x16 pd;  // dropped probabilities (for dV)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ql = acc_row(r, lane);
+            const int qq = q0 + ql;
+            float p = 0.f;
+            if (attn_visible(a, qq, key, lq, lkv)) p = __expf(st[r] * a.scale + kb - lse_s[ql]);
+            const float keep = attn_keep(a, b, h, qq, key);
+            pd[r] = p * keep;
+            st[r] = p * (dp[r] * keep - del_s[ql]);    // dS
+        }
+#pragma unroll
+        for (int s = 0; s < NFR; ++s) {
+            const F pf = acc_to_frag<T>(pd, s);
+            const F sf = acc_to_frag<T>(st, s);
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) {
+                const F dtf = load_kperm_frag<T>(&Dt[(d * 32 + (lane & 31)) * PT], 0, s, hh);
+                mma32(acc_v[d], pf, dtf);
+                const F qtf = load_kperm_frag<T>(&Qt[(d * 32 + (lane & 31)) * PT], 0, s, hh);
+                mma32(acc_k[d], sf, qtf);
+            }
+        }
+    }
+    // accumulators: column = d (lane & 31), row = key (register axis)
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = k0 + wave * 32 + acc_row(r, lane);
+            if (kk >= a.S) continue;
+            const int col = h * HD + d * 32 + (lane & 31);
+            ((T*)a.dk)[(long)b * a.bsdk + (long)kk * a.lddk + col] = from_f32<T>(acc_k[d][r] * a.scale);
+            ((T*)a.dv)[(long)b * a.bsdv + (long)kk * a.lddv + col] = from_f32<T>(acc_v[d][r]);
+        }
+}
+
+template <typename T, int HD> int run_fwd(const AttnArgs& a, hipStream_t s) {
+    dim3 grid(cdiv(a.T, 128), a.H, a.B);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, HD>), grid, dim3(256), 0, s, a);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+template <typename T, int HD> int run_bwd(const AttnArgs& a, hipStream_t s) {
+    long n = (long)a.B * a.H * a.T;
+    hipLaunchKernelGGL((attn_delta_kernel<T, HD>), cdiv(n, 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), dim3(cdiv(a.T, 128), a.H, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD>), dim3(cdiv(a.S, 128), a.H, a.B), dim3(256), 0, s, a);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+int fill_common(AttnArgs& a, int B, int H, int T, int S, int hd, float dropout_p, unsigned long long seed, int causal, int window,
+                const float* key_bias, const int* blk_lq, const int* blk_lkv) {
+    if (B <= 0 || H <= 0 || T <= 0 || S <= 0) return OMR_ERR_ARG;
+    if (hd != 32 && hd != 64) return OMR_ERR_UNSUPPORTED;
+    if (dropout_p < 0.f || dropout_p >= 1.f) return OMR_ERR_ARG;
+    if ((blk_lq == nullptr) != (blk_lkv == nullptr)) return OMR_ERR_ARG;
+    a.B = B; a.H = H; a.T = T; a.S = S; a.scale = 1.0f / sqrtf((float)hd); a.causal = causal; a.window = window;
+    a.key_bias = key_bias; a.blk_lq = blk_lq; a.blk_lkv = blk_lkv;
+    a.drop_thresh = (uint32_t)((double)dropout_p * 4294967296.0);
+    a.drop_scale = 1.f / (1.f - dropout_p);
+    a.seed = seed;
+    return OMR_OK;
+}
+
+}  // namespace
+
+extern "C" int omr_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
+                            long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
+                            const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed,
+                            void* stream) {
+    AttnArgs a = {};
+    int rc = fill_common(a, B, H, T, S, head_dim, dropout_p, seed, causal, window, key_bias, blk_lq, blk_lkv);
+    if (rc) return rc;
+    const int vec = dtype == OMR_BF16 ? 8 : 4;
+    if (ldq % vec || ldk % vec || ldv % vec || ldo % 4) return OMR_ERR_ARG;
+    a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.bsq = bsq; a.bsk = bsk; a.bsv = bsv; a.bso = bso;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == OMR_BF16) return head_dim == 64 ? run_fwd<bf16, 64>(a, s) : run_fwd<bf16, 32>(a, s);
+    if (dtype == OMR_F32) return head_dim == 64 ? run_fwd<float, 64>(a, s) : run_fwd<float, 32>(a, s);
+    return OMR_ERR_UNSUPPORTED;
+}
+
+extern "C" int omr_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                            float* delta_ws, void* dq, void* dk, void* dv, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq,
+                            long lddk, long lddv, long bsq, long bsk, long bsv, long bso, long bsdo, long bsdq, long bsdk, long bsdv, int B,
+                            int H, int T, int S, int head_dim, int causal, int window, const float* key_bias, const int* blk_lq,
+                            const int* blk_lkv, float dropout_p, unsigned long long seed, void* stream) {
+    AttnArgs a = {};
+    int rc = fill_common(a, B, H, T, S, head_dim, dropout_p, seed, causal, window, key_bias, blk_lq, blk_lkv);
+    if (rc) return rc;
+    const int vec = dtype == OMR_BF16 ? 8 : 4;
+    if (ldq % vec || ldk % vec || ldv % vec || lddo % vec) return OMR_ERR_ARG;
+    if (!delta_ws || !lse) return OMR_ERR_ARG;
+    a.q = q; a.k = k; a.v = v; a.o = (void*)o; a.lse = (float*)lse; a.dout = dout; a.delta = delta_ws; a.dq = dq; a.dk = dk; a.dv = dv;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    a.bsq = bsq; a.bsk = bsk; a.bsv = bsv; a.bso = bso; a.bsdo = bsdo; a.bsdq = bsdq; a.bsdk = bsdk; a.bsdv = bsdv;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == OMR_BF16) return head_dim == 64 ? run_bwd<bf16, 64>(a, s) : run_bwd<bf16, 32>(a, s);
+    if (dtype == OMR_F32) return head_dim == 64 ? run_bwd<float, 64>(a, s) : run_bwd<float, 32>(a, s);
+    return OMR_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,557 @@
+// Convolution kernels for the CNN encoder (reference: src/transformer/encoder.py) on gfx950.
+// Activations are NHWC ([B][H][W][C], channel fastest) so that
+//   * the 3x3 convs are nine shifted [pixels x Cin] . [Cin x Cout] MFMA GEMMs fed from ONE LDS halo tile,
+//   * DepthSepConv2D's 1x1 point_conv is a plain GEMM (gemm.hip) and
+//   * the encoder output IS the decoder memory [B, S, C] (model.py:147 flatten+permute) with no copy.
+// Weights are [Cout][3][3][Cin] (= torch channels_last storage of the reference's [Cout,Cin,3,3] tensor).
+//
+//   conv3x3_mfma     forward (stride s, pad 1, optional fused InstanceNorm-apply on the input, bias, ReLU) and,
+//                    with flipped/transposed weights + input dilation, the data gradient (transposed conv).
+//   conv3x3_wgrad    dW[n][tap][c] += sum_pix dY[pix][n] X[pix+tap][c]  (MFMA, K = pixels, fp32 atomics)
+//   conv1_direct     the 1 -> 16 first layer (K = 9: HBM-bound, VALU) forward and weight gradient
+//   dwconv3x3        depthwise 3x3 forward / data gradient / weight gradient (HBM-bound, VALU)
+#include "omr_common.h"
+#include "omr_hip.h"
+
+namespace {
+
+constexpr int TW = 32;  // output tile width = one MFMA M-block (32 pixels of one output row)
+
+struct ConvArgs {
+    const void* x; const void* w; const float* bias; void* y;
+    const float* mean; const float* rstd;        // [B][CIN] fused InstanceNorm apply on load (or null)
+    const void* mask; float mask_scale;          // epilogue: y = mask > 0 ? y * scale : 0   (ReLU/dropout backward of the consumer side)
+    int B, Hr, Wr, CIN, Ho, Wo, COUT;
+    int sh, sw, dh, dw, relu, tiles_w, tiles_h;
+};
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 conv as implicit GEMM.  Block = 256 threads = 4 waves; output tile = (4*RPW) rows x 32 cols x NT
+// couts.  Wave w owns tile rows [w*RPW, (w+1)*RPW) (one M-block each) and all NT/32 N-blocks.
+template <typename T, int NT, int RPW, int CK>
+__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N;
+    constexpr int CKP = CK + VEC;           // pitch (elements): 16-byte odd multiple -> conflict-free b128 reads
+    constexpr int NB = NT / 32;
+    constexpr int TH = 4 * RPW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Xs = reinterpret_cast<T*>(smem_raw);
+    const int IH = (TH - 1) * a.sh + 3, IW = (TW - 1) * a.sw + 3;
+    T* Ws = Xs + (long)IH * IW * CKP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, n0 = blockIdx.y * NT;
+    const int th = blockIdx.x / a.tiles_w, tw = blockIdx.x % a.tiles_w;
+    const int oh0 = th * TH, ow0 = tw * TW;
+    const int vh0 = oh0 * a.sh - 1, vw0 = ow0 * a.sw - 1;           // virtual (dilated) input origin of the halo
+    const int Hv = (a.Hr - 1) * a.dh + 1, Wv = (a.Wr - 1) * a.dw + 1;
+    const T* X = (const T*)a.x + (long)b * a.Hr * a.Wr * a.CIN;
+    const T* W = (const T*)a.w;
+
+    f32x16 acc[RPW][NB];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fk = (lane >> 5) * VEC;
+    constexpr int CPP = CK / VEC;  // 16-byte chunks per pixel per channel chunk
+
+    for (int c0 = 0; c0 < a.CIN; c0 += CK) {
+        __syncthreads();
+        // ---- stage the input halo (zero outside the image and on dilation holes)
+        const int nx = IH * IW * CPP;
+        for (int c = tid; c < nx; c += 256) {
+            const int pix = c / CPP, kc = (c % CPP) * VEC;
+            const int il = pix / IW, jl = pix % IW;
+            const int vh = vh0 + il, vw = vw0 + jl;
+            F v = frag_zero<T>();
+            if (vh >= 0 && vh < Hv && vw >= 0 && vw < Wv && (vh % a.dh) == 0 && (vw % a.dw) == 0) {
+                const int ih = vh / a.dh, iw = vw / a.dw;
+                v = *reinterpret_cast<const F*>(X + ((long)ih * a.Wr + iw) * a.CIN + c0 + kc);
+                if (a.mean) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const int ch = b * a.CIN + c0 + kc + e;
+                        v[e] = from_f32<T>((to_f32(v[e]) - a.mean[ch]) * a.rstd[ch]);
+                    }
+                }
+            }
+            *reinterpret_cast<F*>(Xs + (long)pix * CKP + kc) = v;
+        }
+        // ---- stage the weights of this channel chunk: Ws[n][tap][k]
+        const int nw = NT * 9 * CPP;
+        for (int c = tid; c < nw; c += 256) {
+            const int row = c / CPP, kc = (c % CPP) * VEC;  // row = n*9 + tap
+            const int n = n0 + row / 9;
+            F v = frag_zero<T>();
+            if (n < a.COUT) v = *reinterpret_cast<const F*>(W + ((long)n * 9 + row % 9) * a.CIN + c0 + kc);
+            *reinterpret_cast<F*>(Ws + (long)row * CKP + kc) = v;
+        }
+        __syncthreads();
+        // ---- nine shifted GEMMs out of LDS
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+            for (int kk = 0; kk < CK; kk += KStep<T>::value) {
+                F af[RPW], bf[NB];
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) {
+                    const int r = wave * RPW + i;
+                    const int pix = (r * a.sh + kh) * IW + frow * a.sw + kw;
+                    af[i] = *reinterpret_cast<const F*>(Xs + (long)pix * CKP + kk + fk);
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    bf[j] = *reinterpret_cast<const F*>(Ws + (long)((j * 32 + frow) * 9 + tap) * CKP + kk + fk);
+#pragma unroll
+                for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) mma32(acc[i][j], af[i], bf[j]);
+            }
+        }
+    }
+
+    // ---- epilogue: bias, ReLU, optional mask; lanes 0..31 write 32 consecutive couts of one pixel
+    T* Y = (T*)a.y + (long)b * a.Ho * a.Wo * a.COUT;
+    const T* Mk = a.mask ? (const T*)a.mask + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + j * 32 + (lane & 31);
+        if (n >= a.COUT) continue;
+        const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int oh = oh0 + wave * RPW + i;
+            if (oh >= a.Ho) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ow = ow0 + acc_row(r, lane);
+                if (ow >= a.Wo) continue;
+                float v = acc[i][j][r] + bv;
+                if (a.relu) v = fmaxf(v, 0.f);
+                const long o = ((long)oh * a.Wo + ow) * a.COUT + n;
+                if (Mk) v = to_f32(Mk[o]) > 0.f ? v * a.mask_scale : 0.f;
+                Y[o] = from_f32<T>(v);
+            }
+        }
+    }
+}
+
+template <typename T, int NT, int RPW, int CK> int launch_conv(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    constexpr int TH = 4 * RPW;
+    constexpr int CKP = CK + Frag<T>::N;
+    a.tiles_w = cdiv(a.Wo, TW);
+    a.tiles_h = cdiv(a.Ho, TH);
+    const int IH = (TH - 1) * a.sh + 3, IW = (TW - 1) * a.sw + 3;
+    size_t shm = ((size_t)IH * IW + (size_t)NT * 9) * CKP * sizeof(T);
+    if (shm > 160 * 1024) return OMR_ERR_UNSUPPORTED;
+    auto kern = conv3x3_mfma_kernel<T, NT, RPW, CK>;
+    if (shm > 48 * 1024) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return OMR_ERR_LAUNCH;
+    }
+    dim3 grid(a.tiles_w * a.tiles_h, cdiv(a.COUT, NT), a.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), shm, s, a);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+template <typename T> int dispatch_conv(const ConvArgs& a, hipStream_t s) {
+    constexpr int KS = KStep<T>::value;
+    const bool strided = a.sh > 1 || a.sw > 1;
+    const bool wide = a.COUT > 32;
+    const bool ck2 = !strided && (a.CIN % (2 * KS) == 0);
+    if (a.CIN % KS) return OMR_ERR_UNSUPPORTED;
+    if (strided) {
+        if (wide) return launch_conv<T, 64, 1, KS>(a, s);
+        return launch_conv<T, 32, 1, KS>(a, s);
+    }
+    if (wide) return ck2 ? launch_conv<T, 64, 2, 2 * KS>(a, s) : launch_conv<T, 64, 2, KS>(a, s);
+    return ck2 ? launch_conv<T, 32, 2, 2 * KS>(a, s) : launch_conv<T, 32, 2, KS>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight re-layout for the data gradient: Wd[c][8 - tap][n] = W[n][tap][c]   (transposed conv = conv with
+// flipped taps and swapped channel roles).
+template <typename T>
+__global__ void weight_flip_kernel(const T* __restrict__ w, T* __restrict__ wd, int COUT, int CIN) {
+    long total = (long)COUT * 9 * CIN;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int n = (int)(i % COUT); long q = i / COUT; int tapd = (int)(q % 9); int c = (int)(q / 9);
+        wd[i] = w[((long)n * 9 + (8 - tapd)) * CIN + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 conv.  Workgroup = 2x2 waves; wave (wn, wc) owns the 32 couts x 32 cins
+// block (n0 + 32 wn, c0 + 32 wc) for all nine taps (9 x 16 accumulator registers).  K = output pixels:
+// the block walks pixel tiles (grid-stride), stages dY[pix][64 n] and the X halo [pix][64 c] in LDS
+// and reads k-strided operand fragments element-wise (dtype generic; bf16 tr-reads are a later step).
+struct WgradArgs {
+    const void* x; const void* dy; float* dw;
+    const float* mean; const float* rstd;
+    int B, Hr, Wr, CIN, Ho, Wo, COUT, sh, sw, tiles_w, tiles_h;
+};
+
+template <typename T, int TH, int CBN, int CBC>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N;
+    constexpr int WN = CBN / 32, WC = CBC / 32, WK = 4 / (WN * WC);   // waves over couts, cins and pixel slices
+    constexpr int NP = CBN + 2, CP = CBC + 2;   // LDS pitches (elements)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int IH = (TH - 1) * a.sh + 3, IW = (TW - 1) * a.sw + 3;
+    T* Ys = reinterpret_cast<T*>(smem_raw);            // [TH*TW][NP]
+    T* Xs = Ys + (long)TH * TW * NP;                   // [IH*IW][CP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave / (WN * WC), wn = (wave % (WN * WC)) / WC, wc = wave % WC;
+    const int ncb = cdiv(a.CIN, CBC);
+    const int n0 = (blockIdx.y / ncb) * CBN, c0 = (blockIdx.y % ncb) * CBC;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int ntiles = a.B * a.tiles_h * a.tiles_w;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / (a.tiles_h * a.tiles_w);
+        const int rem = tile % (a.tiles_h * a.tiles_w);
+        const int oh0 = (rem / a.tiles_w) * TH, ow0 = (rem % a.tiles_w) * TW;
+        const int ih0 = oh0 * a.sh - 1, iw0 = ow0 * a.sw - 1;
+        const T* X = (const T*)a.x + (long)b * a.Hr * a.Wr * a.CIN;
+        const T* DY = (const T*)a.dy + (long)b * a.Ho * a.Wo * a.COUT;
+        __syncthreads();
+        for (int c = tid; c < TH * TW * (CBN / VEC); c += 256) {
+            const int pix = c / (CBN / VEC), kc = (c % (CBN / VEC)) * VEC;
+            const int oh = oh0 + pix / TW, ow = ow0 + pix % TW;
+            F v = frag_zero<T>();
+            if (oh < a.Ho && ow < a.Wo && n0 + kc < a.COUT) v = *reinterpret_cast<const F*>(DY + ((long)oh * a.Wo + ow) * a.COUT + n0 + kc);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) Ys[(long)pix * NP + kc + e] = v[e];
+        }
+        for (int c = tid; c < IH * IW * (CBC / VEC); c += 256) {
+            const int pix = c / (CBC / VEC), kc = (c % (CBC / VEC)) * VEC;
+            const int ih = ih0 + pix / IW, iw = iw0 + pix % IW;
+            F v = frag_zero<T>();
+            if (ih >= 0 && ih < a.Hr && iw >= 0 && iw < a.Wr && c0 + kc < a.CIN) {
+                v = *reinterpret_cast<const F*>(X + ((long)ih * a.Wr + iw) * a.CIN + c0 + kc);
+                if (a.mean) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const int ch = b * a.CIN + c0 + kc + e;
+                        v[e] = from_f32<T>((to_f32(v[e]) - a.mean[ch]) * a.rstd[ch]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) Xs[(long)pix * CP + kc + e] = v[e];
+        }
+        __syncthreads();
+        const int nl = wn * 32 + (lane & 31), cl = wc * 32 + (lane & 31);
+        for (int k0 = wk * KStep<T>::value; k0 < TH * TW; k0 += WK * KStep<T>::value) {
+            const int pbase = k0 + (lane >> 5) * VEC;     // VEC consecutive pixels of one tile row
+            const int r = pbase / TW, col = pbase % TW;
+            F af;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) af[e] = Ys[(long)(pbase + e) * NP + nl];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap % 3;
+                F bf;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) bf[e] = Xs[(long)((r * a.sh + kh) * IW + (col + e) * a.sw + kw) * CP + cl];
+                mma32(acc[tap], af, bf);
+            }
+        }
+    }
+    // accumulate: dw[n][tap][c] (fp32 atomics; the grad buffer is zeroed once per step)
+    const int c = c0 + wc * 32 + (lane & 31);
+    if (c < a.CIN) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 32 + acc_row(r, lane);
+                if (n < a.COUT) atomicAdd(&a.dw[((long)n * 9 + tap) * a.CIN + c], acc[tap][r]);
+            }
+    }
+}
+
+template <typename T, int TH, int CBN, int CBC> int launch_wgrad2(WgradArgs a, hipStream_t s) {
+    a.tiles_w = cdiv(a.Wo, TW);
+    a.tiles_h = cdiv(a.Ho, TH);
+    const int IH = (TH - 1) * a.sh + 3, IW = (TW - 1) * a.sw + 3;
+    size_t shm = ((size_t)TH * TW * (CBN + 2) + (size_t)IH * IW * (CBC + 2)) * sizeof(T);
+    if (shm > 160 * 1024) return OMR_ERR_UNSUPPORTED;
+    auto kern = conv3x3_wgrad_kernel<T, TH, CBN, CBC>;
+    if (shm > 48 * 1024) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return OMR_ERR_LAUNCH;
+    }
+    const int gy = cdiv(a.COUT, CBN) * cdiv(a.CIN, CBC);
+    const int ntiles = a.B * a.tiles_h * a.tiles_w;
+    int gx = 1024 / gy; if (gx < 1) gx = 1; if (gx > ntiles) gx = ntiles;
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), shm, s, a);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+template <typename T, int TH> int launch_wgrad(const WgradArgs& a, hipStream_t s) {
+    if (a.COUT > 32 && a.CIN > 32) return launch_wgrad2<T, TH, 64, 64>(a, s);
+    if (a.COUT > 32) return launch_wgrad2<T, TH, 64, 32>(a, s);
+    return launch_wgrad2<T, TH, 32, 32>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// First layer: Cin = 1 -> COUT (<= 32) with ReLU.  One thread per output pixel; K = 9, HBM-bound.
+template <typename T, int COUT>
+__global__ void conv1_direct_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, int B,
+                                    int H, int Wd, int relu) {
+    __shared__ float ws[COUT * 9 + COUT];
+    for (int i = threadIdx.x; i < COUT * 9; i += blockDim.x) ws[i] = to_f32(w[i]);
+    for (int i = threadIdx.x; i < COUT; i += blockDim.x) ws[COUT * 9 + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const long total = (long)B * H * Wd;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(p % Wd); const long q = p / Wd; const int i = (int)(q % H); const long b = q / H;
+        float in[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ii = i + t / 3 - 1, jj = j + t % 3 - 1;
+            in[t] = (ii >= 0 && ii < H && jj >= 0 && jj < Wd) ? to_f32(x[(b * H + ii) * Wd + jj]) : 0.f;
+        }
+        T out[COUT];
+#pragma unroll
+        for (int n = 0; n < COUT; ++n) {
+            float s = ws[COUT * 9 + n];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) s += ws[n * 9 + t] * in[t];
+            out[n] = from_f32<T>(relu ? fmaxf(s, 0.f) : s);
+        }
+        typedef typename Frag<T>::type F;
+        F* dst = reinterpret_cast<F*>(y + p * COUT);
+#pragma unroll
+        for (int v = 0; v < COUT / Frag<T>::N; ++v) {
+            F f;
+#pragma unroll
+            for (int e = 0; e < Frag<T>::N; ++e) f[e] = out[v * Frag<T>::N + e];
+            dst[v] = f;
+        }
+    }
+}
+// dW[n][tap] += sum_p dY[p][n] x[p + tap];  thread = (channel n = tid % COUT, pixel phase)
+template <typename T, int COUT>
+__global__ void conv1_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, int B, int H, int Wd) {
+    __shared__ float red[COUT * 9];
+    for (int i = threadIdx.x; i < COUT * 9; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    const int n = threadIdx.x % COUT, phase = threadIdx.x / COUT, nphase = blockDim.x / COUT;
+    const long total = (long)B * H * Wd;
+    float accw[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) accw[t] = 0.f;
+    for (long p = (long)blockIdx.x * nphase + phase; p < total; p += (long)gridDim.x * nphase) {
+        const int j = (int)(p % Wd); const long q = p / Wd; const int i = (int)(q % H); const long b = q / H;
+        const float g = to_f32(dy[p * COUT + n]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ii = i + t / 3 - 1, jj = j + t % 3 - 1;
+            const float xv = (ii >= 0 && ii < H && jj >= 0 && jj < Wd) ? to_f32(x[(b * H + ii) * Wd + jj]) : 0.f;
+            accw[t] += g * xv;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) atomicAdd(&red[n * 9 + t], accw[t]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < COUT * 9; i += blockDim.x) atomicAdd(&dw[i], red[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise 3x3, stride 1, pad 1 on NHWC (DepthSepConv2D.depth_conv, encoder.py:56-64).  One thread =
+// one pixel x VEC channels.  flip=1 applies the taps mirrored (data gradient).  Optional fused
+// InstanceNorm apply on the input and optional epilogue mask (ReLU/dropout backward of the producer).
+template <typename T>
+__global__ void dwconv3x3_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y,
+                                 const float* __restrict__ mean, const float* __restrict__ rstd, const T* __restrict__ mask, float mask_scale,
+                                 int B, int H, int Wd, int C, int flip) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N;
+    const int cv = C / VEC;
+    const long total = (long)B * H * Wd * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VEC; long p = i / cv;
+        const int j = (int)(p % Wd); long q = p / Wd; const int ii = (int)(q % H); const long b = q / H;
+        float s[VEC], mu[VEC], rs[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            s[e] = bias ? bias[c + e] : 0.f;
+            mu[e] = mean ? mean[b * C + c + e] : 0.f;
+            rs[e] = rstd ? rstd[b * C + c + e] : 1.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = ii + t / 3 - 1, xx = j + t % 3 - 1;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= Wd) continue;
+            const F v = *reinterpret_cast<const F*>(x + ((b * H + yy) * Wd + xx) * C + c);
+            const int tw = flip ? 8 - t : t;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s[e] += to_f32(w[(c + e) * 9 + tw]) * ((to_f32(v[e]) - mu[e]) * rs[e]);
+        }
+        F o;
+        if (mask) {
+            const F mk = *reinterpret_cast<const F*>(mask + p * C + c);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(to_f32(mk[e]) > 0.f ? s[e] * mask_scale : 0.f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(s[e]);
+        }
+        *reinterpret_cast<F*>(y + p * C + c) = o;
+    }
+}
+
+// dW[c][tap] += sum_p dY[p][c] xin[p+tap][c];  db[c] += sum_p dY[p][c].  Block = 256 threads covers
+// channels (tid % C-group) x pixel phases; LDS reduction then one fp32 atomic per (c, tap) per block.
+template <typename T>
+__global__ void dwconv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db,
+                                       const float* __restrict__ mean, const float* __restrict__ rstd, int B, int H, int Wd, int C,
+                                       int pix_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [C][10]
+    for (int i = threadIdx.x; i < C * 10; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    const bool wide = (int)blockDim.x >= C;
+    const int cstride = wide ? C : (int)blockDim.x;
+    const int nphase = wide ? (int)blockDim.x / C : 1;
+    const int phase = wide ? (int)threadIdx.x / C : 0;
+    const long total = (long)B * H * Wd;
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    const long p1 = p0 + pix_per_block < total ? p0 + pix_per_block : total;
+    if (phase < nphase) {
+        for (int c = threadIdx.x % cstride; c < C; c += cstride) {
+            float a[10];
+#pragma unroll
+            for (int t = 0; t < 10; ++t) a[t] = 0.f;
+            for (long p = p0 + phase; p < p1; p += nphase) {
+                const int j = (int)(p % Wd); const long q = p / Wd; const int ii = (int)(q % H); const long b = q / H;
+                const float g = to_f32(dy[p * C + c]);
+                const float mu = mean ? mean[b * C + c] : 0.f, rs = rstd ? rstd[b * C + c] : 1.f;
+                a[9] += g;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = ii + t / 3 - 1, xx = j + t % 3 - 1;
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= Wd) continue;
+                    a[t] += g * ((to_f32(x[((b * H + yy) * Wd + xx) * C + c]) - mu) * rs);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 10; ++t) atomicAdd(&red[c * 10 + t], a[t]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 10; i += blockDim.x) {
+        const int c = i / 10, t = i % 10;
+        if (t < 9) atomicAdd(&dw[c * 9 + t], red[i]);
+        else if (db) atomicAdd(&db[c], red[i]);
+    }
+}
+
+inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                         \
+    if ((dtype) == OMR_F32) { typedef float T; CALL; }  \
+    else if ((dtype) == OMR_BF16) { typedef bf16 T; CALL; } \
+    else return OMR_ERR_UNSUPPORTED;
+
+extern "C" int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const float* bias, void* y, const float* in_mean, const float* in_rstd,
+                               const void* out_mask, float mask_scale, int B, int H, int W, int CIN, int COUT, int stride_h, int stride_w,
+                               int dil_h, int dil_w, int Ho, int Wo, int relu, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || CIN <= 0 || COUT <= 0 || !x || !w || !y) return OMR_ERR_ARG;
+    if (stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1) return OMR_ERR_ARG;
+    if ((stride_h > 1 || stride_w > 1) && (dil_h > 1 || dil_w > 1)) return OMR_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (CIN == 1) {
+        if (dil_h != 1 || dil_w != 1 || stride_h != 1 || stride_w != 1 || in_mean || out_mask || Ho != H || Wo != W) return OMR_ERR_UNSUPPORTED;
+        long total = (long)B * H * W;
+        DISPATCH_T(dtype, {
+            if (COUT == 16) hipLaunchKernelGGL((conv1_direct_kernel<T, 16>), ew_grid(total), 256, 0, s, (const T*)x, (const T*)w, bias, (T*)y, B, H, W, relu);
+            else if (COUT == 32) hipLaunchKernelGGL((conv1_direct_kernel<T, 32>), ew_grid(total), 256, 0, s, (const T*)x, (const T*)w, bias, (T*)y, B, H, W, relu);
+            else return OMR_ERR_UNSUPPORTED;
+        });
+        OMR_CHECK_LAUNCH();
+        return OMR_OK;
+    }
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.mean = in_mean; a.rstd = in_rstd; a.mask = out_mask; a.mask_scale = mask_scale;
+    a.B = B; a.Hr = H; a.Wr = W; a.CIN = CIN; a.Ho = Ho; a.Wo = Wo; a.COUT = COUT;
+    a.sh = stride_h; a.sw = stride_w; a.dh = dil_h; a.dw = dil_w; a.relu = relu; a.tiles_w = a.tiles_h = 0;
+    DISPATCH_T(dtype, return dispatch_conv<T>(a, s));
+}
+
+extern "C" int omr_conv3x3_weight_flip(int dtype, const void* w, void* wd, int COUT, int CIN, void* stream) {
+    if (COUT <= 0 || CIN <= 0) return OMR_ERR_ARG;
+    long total = (long)COUT * 9 * CIN;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((weight_flip_kernel<T>), ew_grid(total), 256, 0, (hipStream_t)stream, (const T*)w, (T*)wd, COUT, CIN));
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, const float* in_mean, const float* in_rstd, int B, int H,
+                                 int W, int CIN, int COUT, int stride_h, int stride_w, int Ho, int Wo, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || CIN <= 0 || COUT <= 0 || !x || !dy || !dw) return OMR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (CIN == 1) {
+        if (stride_h != 1 || stride_w != 1 || in_mean) return OMR_ERR_UNSUPPORTED;
+        long total = (long)B * H * W;
+        int grid = (int)((total + 4095) / 4096); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+        DISPATCH_T(dtype, {
+            if (COUT == 16) hipLaunchKernelGGL((conv1_wgrad_kernel<T, 16>), grid, 256, 0, s, (const T*)x, (const T*)dy, dw, B, H, W);
+            else if (COUT == 32) hipLaunchKernelGGL((conv1_wgrad_kernel<T, 32>), grid, 256, 0, s, (const T*)x, (const T*)dy, dw, B, H, W);
+            else return OMR_ERR_UNSUPPORTED;
+        });
+        OMR_CHECK_LAUNCH();
+        return OMR_OK;
+    }
+    const int vec = dtype == OMR_BF16 ? 8 : 4;
+    if (CIN % vec || COUT % vec) return OMR_ERR_UNSUPPORTED;
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.dw = dw; a.mean = in_mean; a.rstd = in_rstd; a.B = B; a.Hr = H; a.Wr = W; a.CIN = CIN; a.Ho = Ho; a.Wo = Wo;
+    a.COUT = COUT; a.sh = stride_h; a.sw = stride_w; a.tiles_w = a.tiles_h = 0;
+    const bool strided = stride_h > 1 || stride_w > 1;
+    if (dtype == OMR_BF16) return strided ? launch_wgrad<bf16, 4>(a, s) : launch_wgrad<bf16, 8>(a, s);
+    if (dtype == OMR_F32) return strided ? launch_wgrad<float, 2>(a, s) : launch_wgrad<float, 4>(a, s);
+    return OMR_ERR_UNSUPPORTED;
+}
+
+extern "C" int omr_dwconv3x3(int dtype, const void* x, const void* w, const float* bias, void* y, const float* in_mean, const float* in_rstd,
+                             const void* out_mask, float mask_scale, int B, int H, int W, int C, int flip, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return OMR_ERR_ARG;
+    const int vec = dtype == OMR_BF16 ? 8 : 4;
+    if (C % vec) return OMR_ERR_UNSUPPORTED;
+    long total = (long)B * H * W * (C / vec);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T>), ew_grid(total), 256, 0, (hipStream_t)stream, (const T*)x, (const T*)w, bias, (T*)y,
+                                         in_mean, in_rstd, (const T*)out_mask, mask_scale, B, H, W, C, flip));
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, const float* in_mean, const float* in_rstd,
+                                   int B, int H, int W, int C, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return OMR_ERR_ARG;
+    long total = (long)B * H * W;
+    int ppb = 512;
+    int grid = (int)((total + ppb - 1) / ppb);
+    size_t shm = (size_t)C * 10 * sizeof(float);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<T>), grid, 256, shm, (hipStream_t)stream, (const T*)x, (const T*)dy, dw, db,
+                                         in_mean, in_rstd, B, H, W, C, ppb));
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}

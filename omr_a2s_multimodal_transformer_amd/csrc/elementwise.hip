@@ -1,0 +1,246 @@
+// HBM-bound elementwise / gather / reduction kernels (gfx950): 16-byte vector access per lane,
+// grid-stride loops capped at 2048 blocks (256 CUs x 8).
+#include "omr_common.h"
+#include "omr_hip.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+inline int ew_grid(long nvec) { long g = (nvec + EW_BLOCK - 1) / EW_BLOCK; return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
+
+template <typename T> struct Vec {
+    typedef typename Frag<T>::type type;
+    static constexpr int N = Frag<T>::N;
+};
+
+// ---------------------------------------------------------------- cast
+template <typename TS, typename TD> __global__ void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        d[i] = from_f32<TD>(to_f32(s[i]));
+}
+
+// ---------------------------------------------------------------- out = a + b
+template <typename T> __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long n) {
+    typedef typename Vec<T>::type V;
+    constexpr int N = Vec<T>::N;
+    long nv = n / N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+        V x = reinterpret_cast<const V*>(a)[i], y = reinterpret_cast<const V*>(b)[i], z;
+#pragma unroll
+        for (int e = 0; e < N; ++e) z[e] = from_f32<T>(to_f32(x[e]) + to_f32(y[e]));
+        reinterpret_cast<V*>(o)[i] = z;
+    }
+    if (blockIdx.x == 0)
+        for (long i = nv * N + threadIdx.x; i < n; i += blockDim.x) o[i] = from_f32<T>(to_f32(a[i]) + to_f32(b[i]));
+}
+
+// ---------------------------------------------------------------- dx = dy * (y > 0) * scale   (ReLU [+dropout] backward)
+template <typename T> __global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, long n, float scale) {
+    typedef typename Vec<T>::type V;
+    constexpr int N = Vec<T>::N;
+    long nv = n / N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+        V g = reinterpret_cast<const V*>(dy)[i], yy = reinterpret_cast<const V*>(y)[i], z;
+#pragma unroll
+        for (int e = 0; e < N; ++e) z[e] = from_f32<T>(to_f32(yy[e]) > 0.f ? to_f32(g[e]) * scale : 0.f);
+        reinterpret_cast<V*>(dx)[i] = z;
+    }
+    if (blockIdx.x == 0)
+        for (long i = nv * N + threadIdx.x; i < n; i += blockDim.x)
+            dx[i] = from_f32<T>(to_f32(y[i]) > 0.f ? to_f32(dy[i]) * scale : 0.f);
+}
+
+// ---------------------------------------------------------------- dropout (elementwise, or per (b, channel) for Dropout2d on NHWC)
+// out = keep ? x / (1-p) : 0.   channel_mode: the mask index is b*C + c (nn.Dropout2d zeroes whole
+// channels, encoder.py:99); otherwise the flat element index.
+template <typename T> __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ o, long n, uint32_t thresh, float scale,
+                                                     uint64_t seed, int channel_mode, long per_sample, int C) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        uint64_t idx = channel_mode ? (uint64_t)((i / per_sample) * C + (i % C)) : (uint64_t)i;
+        o[i] = drop_keep(seed, idx, thresh) ? from_f32<T>(to_f32(x[i]) * scale) : from_f32<T>(0.f);
+    }
+}
+
+// ---------------------------------------------------------------- embedding gather + 1-D positional encoding
+// out[m, :] = table[tok[m], :] + pe[m % T, :]      (decoder.py:124; no sqrt(d) scaling)
+template <typename T> __global__ void embed_pe_kernel(const long* __restrict__ tok, const T* __restrict__ table, const float* __restrict__ pe,
+                                                      T* __restrict__ out, long M, int Tlen, int d, int vocab) {
+    long total = M * d;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / d; int c = (int)(i % d);
+        long t = tok[m];
+        float e = (t >= 0 && t < vocab) ? to_f32(table[t * d + c]) : 0.f;
+        out[i] = from_f32<T>(e + pe[(m % Tlen) * d + c]);
+    }
+}
+// dTable[tok[m], :] += dOut[m, :]   (fp32 atomics; the PAD row gets no gradient: nn.Embedding padding_idx)
+template <typename T> __global__ void embed_bwd_kernel(const long* __restrict__ tok, const T* __restrict__ dout, float* __restrict__ dtable,
+                                                       long M, int d, int pad_idx, int vocab) {
+    long total = M * d;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / d; int c = (int)(i % d);
+        long t = tok[m];
+        if (t == pad_idx || t < 0 || t >= vocab) continue;
+        atomicAdd(&dtable[t * d + c], to_f32(dout[i]));
+    }
+}
+
+// ---------------------------------------------------------------- 2-D positional encoding on NHWC feature maps
+// out[b,i,j,c] = x[b,i,j,c] + pe[i,j,c]  with pe stored [maxh][maxw][C]   (model.py:45-47 then flatten :147)
+template <typename T> __global__ void add_pe2d_kernel(const T* __restrict__ x, const float* __restrict__ pe, T* __restrict__ out,
+                                                      int B, int h, int w, int C, int maxw) {
+    long total = (long)B * h * w * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C); long p = i / C; int j = (int)(p % w); long q = p / w; int ii = (int)(q % h);
+        out[i] = from_f32<T>(to_f32(x[i]) + pe[((long)ii * maxw + j) * C + c]);
+    }
+}
+
+// ---------------------------------------------------------------- column sums:  db[n] += sum_m dY[m, n]   (bias gradients)
+// One block handles a 64-row slab x 256 columns; fp32 atomics into db.
+template <typename T> __global__ void colsum_kernel(const T* __restrict__ dy, float* __restrict__ db, long M, int N, long ld, int rows_per_block) {
+    int col = blockIdx.x * blockDim.x + threadIdx.x;
+    long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    if (col >= N) return;
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += to_f32(dy[r * ld + col]);
+    atomicAdd(&db[col], s);
+}
+
+// ---------------------------------------------------------------- fused Adam over one flat buffer
+// torch optim/adam.py:347 single-tensor math (model.py:134-139: lr 1e-4, betas (0.9,0.999), eps 1e-8):
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// Optionally writes the bf16 compute copy of the updated parameter in the same pass.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            bf16* __restrict__ p_lp, long n, float lr_over_bc1, float b1, float b2, float eps, float inv_sqrt_bc2, float gscale) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i] * gscale;
+        float mi = b1 * m[i] + (1.f - b1) * gi;
+        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        float pi = p[i] - lr_over_bc1 * (mi / denom);
+        m[i] = mi; v[i] = vi; p[i] = pi;
+        if (p_lp) p_lp[i] = (bf16)pi;
+    }
+}
+
+// ---------------------------------------------------------------- argmax over one fp32 vector (greedy decode, model.py:187)
+// First-max-index tie rule (torch.argmax).  Also returns top-1 value (model.py:253 topk(1)).
+__global__ void argmax_kernel(const float* __restrict__ x, int n, long* __restrict__ idx_out, float* __restrict__ val_out) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = x[i];
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+    sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            float v2 = sv[threadIdx.x + o]; int i2 = si[threadIdx.x + o];
+            if (v2 > sv[threadIdx.x] || (v2 == sv[threadIdx.x] && i2 < si[threadIdx.x])) { sv[threadIdx.x] = v2; si[threadIdx.x] = i2; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { idx_out[0] = si[0]; if (val_out) val_out[0] = sv[0]; }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                         \
+    if ((dtype) == OMR_F32) { typedef float T; CALL; }  \
+    else if ((dtype) == OMR_BF16) { typedef bf16 T; CALL; } \
+    else return OMR_ERR_UNSUPPORTED;
+
+extern "C" int omr_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream) {
+    if (n <= 0) return OMR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = ew_grid(n);
+    if (src_dtype == OMR_F32 && dst_dtype == OMR_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), grid, EW_BLOCK, 0, s, (const float*)src, (bf16*)dst, n);
+    else if (src_dtype == OMR_BF16 && dst_dtype == OMR_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), grid, EW_BLOCK, 0, s, (const bf16*)src, (float*)dst, n);
+    else if (src_dtype == OMR_F32 && dst_dtype == OMR_F32) hipLaunchKernelGGL((cast_kernel<float, float>), grid, EW_BLOCK, 0, s, (const float*)src, (float*)dst, n);
+    else if (src_dtype == OMR_BF16 && dst_dtype == OMR_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), grid, EW_BLOCK, 0, s, (const bf16*)src, (bf16*)dst, n);
+    else return OMR_ERR_UNSUPPORTED;
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_add(int dtype, const void* a, const void* b, void* out, long n, void* stream) {
+    if (n <= 0) return OMR_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((add_kernel<T>), ew_grid(n / Frag<T>::N + 1), EW_BLOCK, 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)out, n));
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_relu_bwd(int dtype, const void* dy, const void* y, void* dx, long n, float scale, void* stream) {
+    if (n <= 0) return OMR_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((relu_bwd_kernel<T>), ew_grid(n / Frag<T>::N + 1), EW_BLOCK, 0, (hipStream_t)stream, (const T*)dy, (const T*)y, (T*)dx, n, scale));
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_dropout(int dtype, const void* x, void* out, long n, float p, unsigned long long seed, int channel_mode,
+                           long per_sample, int C, void* stream) {
+    if (n <= 0) return OMR_OK;
+    if (p < 0.f || p >= 1.f) return OMR_ERR_ARG;
+    uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    float scale = 1.f / (1.f - p);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), ew_grid(n), EW_BLOCK, 0, (hipStream_t)stream, (const T*)x, (T*)out, n, thresh, scale,
+                                         (uint64_t)seed, channel_mode, per_sample, C));
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_embed_pe_fwd(int dtype, const long* tokens, const void* table, const float* pe, void* out, long M, int T_len, int d,
+                                int vocab, void* stream) {
+    if (M <= 0 || d <= 0 || T_len <= 0) return OMR_ERR_ARG;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((embed_pe_kernel<T>), ew_grid(M * d), EW_BLOCK, 0, (hipStream_t)stream, tokens, (const T*)table, pe, (T*)out, M, T_len, d, vocab));
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_embed_bwd(int dtype, const long* tokens, const void* dout, float* dtable, long M, int d, int pad_idx, int vocab,
+                             void* stream) {
+    if (M <= 0 || d <= 0) return OMR_ERR_ARG;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((embed_bwd_kernel<T>), ew_grid(M * d), EW_BLOCK, 0, (hipStream_t)stream, tokens, (const T*)dout, dtable, M, d, pad_idx, vocab));
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_add_pe2d(int dtype, const void* x, const float* pe_hwc, void* out, int B, int h, int w, int C, int maxh, int maxw,
+                            void* stream) {
+    if (B <= 0 || h <= 0 || w <= 0 || C <= 0) return OMR_ERR_ARG;
+    if (h > maxh || w > maxw) return OMR_ERR_ARG;  // feature map larger than the PE table
+    DISPATCH_T(dtype, hipLaunchKernelGGL((add_pe2d_kernel<T>), ew_grid((long)B * h * w * C), EW_BLOCK, 0, (hipStream_t)stream, (const T*)x, pe_hwc, (T*)out, B, h, w, C, maxw));
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_colsum(int dtype, const void* dy, float* db, long M, int N, long ld, void* stream) {
+    if (M <= 0 || N <= 0) return OMR_ERR_ARG;
+    int rpb = 256;
+    dim3 grid(cdiv(N, 256), cdiv(M, rpb));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, 256, 0, (hipStream_t)stream, (const T*)dy, db, M, N, ld, rpb));
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_adam(float* p, const float* g, float* m, float* v, void* p_bf16, long n, int step, float lr, float b1, float b2,
+                        float eps, float grad_scale, void* stream) {
+    if (n <= 0) return OMR_OK;
+    if (step < 1) return OMR_ERR_ARG;
+    double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    hipLaunchKernelGGL(adam_kernel, ew_grid(n), EW_BLOCK, 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16, n, (float)(lr / bc1), b1, b2, eps,
+                       (float)(1.0 / sqrt(bc2)), grad_scale);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_argmax(const float* x, int n, long* idx_out, float* val_out, void* stream) {
+    if (n <= 0) return OMR_ERR_ARG;
+    hipLaunchKernelGGL(argmax_kernel, 1, 256, 0, (hipStream_t)stream, x, n, idx_out, val_out);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}

@@ -1,0 +1,210 @@
+// Generic MFMA GEMM for gfx950:  C[M,N] (+)= act( opA(A) . opB(B)^T + bias[N] )
+//
+// Canonical ("NT") operand form: A is [M][K] and B is [N][K], both k-contiguous.  transA / transB
+// mean the operand is stored reduction-major instead ([K][M] / [K][N]); the tile is transposed
+// while it is staged into LDS so the MFMA fragment reads are always 16-byte k-contiguous.
+//   linear forward      Y  = X  . W^T + b      (NT)            torch nn/modules/transformer.py:1158-1199
+//   linear input grad   dX = dY . W            (transB)
+//   linear weight grad  dW = dY^T . X          (transA+transB, split-K, fp32 atomic accumulate)
+//   1x1 "point_conv" of DepthSepConv2D (encoder.py:65-70) on NHWC activations = the same GEMMs
+//   Conv1d(k=1) head (decoder.py:98-102)       = the same GEMM with N = vocabulary
+// Block tile 128x128, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 blocks; BK = 2 k-steps.
+#include "omr_common.h"
+#include "omr_hip.h"
+
+namespace {
+
+struct GemmArgs {
+    const void* A; const void* B; void* C; const float* bias;
+    int M, N, K; long lda, ldb, ldc;
+    int relu, accum, atomic, ksplit_len;
+};
+
+constexpr int BM = 128, BN = 128;
+
+template <typename T> struct GemmCfg {
+    static constexpr int VEC = Frag<T>::N;
+    static constexpr int BK = 2 * KStep<T>::value;          // 32 (bf16) / 16 (fp32): 64 B per row
+    static constexpr int PITCH = BK + VEC;                   // 80 B pitch: conflict-free b128 reads
+    static constexpr int CHUNKS_PER_ROW = BK / VEC;          // 4
+};
+
+template <typename T> __device__ __forceinline__ typename Frag<T>::type load_chunk_guard(
+    const T* p, int valid)  // valid = number of leading elements that are in range (<= 0: none)
+{
+    typedef typename Frag<T>::type F;
+    if (valid <= 0) return frag_zero<T>();
+    F v = *reinterpret_cast<const F*>(p);
+    if (valid < Frag<T>::N) {
+#pragma unroll
+        for (int i = 0; i < Frag<T>::N; ++i)
+            if (i >= valid) v[i] = from_f32<T>(0.f);
+    }
+    return v;
+}
+
+// Stage one operand tile (rows x BK) into LDS.  TR=false: src is [rows][K] k-contiguous.
+// TR=true: src is [K][rows] (rows contiguous).  Two 16-byte chunks per thread.
+template <typename T, bool TR> struct Stager {
+    typedef GemmCfg<T> Cfg;
+    typedef typename Frag<T>::type F;
+    F r[2];
+    __device__ __forceinline__ void load(const T* src, long ld, int row0, int nrows, int k0, int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int c = tid + i * 256;
+            if (!TR) {
+                int row = c / Cfg::CHUNKS_PER_ROW, kc = (c % Cfg::CHUNKS_PER_ROW) * Cfg::VEC;
+                int gr = row0 + row, gk = k0 + kc;
+                r[i] = (gr < nrows) ? load_chunk_guard<T>(src + (long)gr * ld + gk, kend - gk) : frag_zero<T>();
+            } else {
+                constexpr int CPR = 128 / Cfg::VEC;  // chunks along the 128 tile rows, per k
+                int k = c / CPR, rc = (c % CPR) * Cfg::VEC;
+                int gk = k0 + k, gr = row0 + rc;
+                r[i] = (gk < kend) ? load_chunk_guard<T>(src + (long)gk * ld + gr, nrows - gr) : frag_zero<T>();
+            }
+        }
+    }
+    __device__ __forceinline__ void store(T* lds, int tid) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int c = tid + i * 256;
+            if (!TR) {
+                int row = c / Cfg::CHUNKS_PER_ROW, kc = (c % Cfg::CHUNKS_PER_ROW) * Cfg::VEC;
+                *reinterpret_cast<F*>(lds + row * Cfg::PITCH + kc) = r[i];
+            } else {
+                constexpr int CPR = 128 / Cfg::VEC;
+                int k = c / CPR, rc = (c % CPR) * Cfg::VEC;
+#pragma unroll
+                for (int e = 0; e < Cfg::VEC; ++e) lds[(rc + e) * Cfg::PITCH + k] = r[i][e];
+            }
+        }
+    }
+};
+
+template <typename T, typename TC, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    typedef GemmCfg<T> Cfg;
+    typedef typename Frag<T>::type F;
+    __shared__ __attribute__((aligned(16))) T As[BM * Cfg::PITCH];
+    __shared__ __attribute__((aligned(16))) T Bs[BN * Cfg::PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.ksplit_len;
+    const int kend = min(g.K, kbeg + g.ksplit_len);
+    const T* A = (const T*)g.A;
+    const T* B = (const T*)g.B;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Stager<T, TA> sa;
+    Stager<T, TB> sb;
+    sa.load(A, g.lda, m0, g.M, kbeg, kend, tid);
+    sb.load(B, g.ldb, n0, g.N, kbeg, kend, tid);
+    sa.store(As, tid);
+    sb.store(Bs, tid);
+    __syncthreads();
+
+    const int frow = lane & 31, fk = (lane >> 5) * Cfg::VEC;
+    for (int k0 = kbeg; k0 < kend; k0 += Cfg::BK) {
+        const bool more = (k0 + Cfg::BK) < kend;
+        if (more) {
+            sa.load(A, g.lda, m0, g.M, k0 + Cfg::BK, kend, tid);
+            sb.load(B, g.ldb, n0, g.N, k0 + Cfg::BK, kend, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < Cfg::BK; ks += KStep<T>::value) {
+            F a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                a[i] = *reinterpret_cast<const F*>(&As[(wm * 64 + i * 32 + frow) * Cfg::PITCH + ks + fk]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                b[j] = *reinterpret_cast<const F*>(&Bs[(wn * 64 + j * 32 + frow) * Cfg::PITCH + ks + fk]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma32(acc[i][j], a[i], b[j]);
+        }
+        __syncthreads();
+        if (more) {
+            sa.store(As, tid);
+            sb.store(Bs, tid);
+            __syncthreads();
+        }
+    }
+
+    TC* C = (TC*)g.C;
+    const int col_l = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + col_l;
+        if (col >= g.N) continue;
+        const float bv = (g.bias != nullptr && blockIdx.z == 0) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                if (row >= g.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (g.relu) v = fmaxf(v, 0.f);
+                TC* dst = C + (long)row * g.ldc + col;
+                if (g.atomic) {
+                    if constexpr (sizeof(TC) == 4) atomicAdd((float*)dst, v);
+                } else if (g.accum) {
+                    *dst = from_f32<TC>(to_f32(*dst) + v);
+                } else {
+                    *dst = from_f32<TC>(v);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, typename TC> int launch(const GemmArgs& g, int ta, int tb, int splits, hipStream_t s) {
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), splits), block(256);
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, TC, false, false>), grid, block, 0, s, g);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, TC, false, true>), grid, block, 0, s, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, TC, true, false>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<T, TC, true, true>), grid, block, 0, s, g);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+}  // namespace
+
+extern "C" int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, int N, int K, const void* A, long lda,
+                        const void* B, long ldb, void* C, long ldc, const float* bias, int relu, int accumulate,
+                        int split_k, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return OMR_ERR_ARG;
+    const int vec = dtype == OMR_BF16 ? 8 : 4;
+    if (lda % vec || ldb % vec) return OMR_ERR_ARG;                       // 16-byte aligned rows
+    if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return OMR_ERR_ARG;
+    if (split_k < 1) split_k = 1;
+    if (split_k > 1 && c_dtype != OMR_F32) return OMR_ERR_ARG;            // split-K accumulates with fp32 atomics
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.relu = relu; g.accum = accumulate; g.atomic = split_k > 1;
+    const int bk = dtype == OMR_BF16 ? 32 : 16;
+    int len = cdiv(cdiv(K, split_k), bk) * bk;
+    g.ksplit_len = len;
+    int splits = cdiv(K, len);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == OMR_BF16) {
+        if (c_dtype == OMR_BF16) return launch<bf16, bf16>(g, transA, transB, splits, s);
+        return launch<bf16, float>(g, transA, transB, splits, s);
+    } else if (dtype == OMR_F32) {
+        if (c_dtype != OMR_F32) return OMR_ERR_UNSUPPORTED;
+        return launch<float, float>(g, transA, transB, splits, s);
+    }
+    return OMR_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,254 @@
+// Normalisation kernels (gfx950), all statistics in fp32/fp64:
+//   InstanceNorm2d(eps=1e-3, affine=False, no running stats) on NHWC maps  -- encoder.py:151-156,210-215
+//   residual + LayerNorm(eps=1e-5) of the post-norm decoder layer          -- torch nn/modules/transformer.py:1146-1154
+#include "omr_common.h"
+#include "omr_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm statistics over x[B][HW][C] (NHWC): per (b, c) mean and 1/sqrt(biased var + eps).
+// Stage 1: each block reduces a slab of pixels for all channels; per-thread fp32 partials over a
+// short run, then fp64 atomics into ws[b][c][2] (sum, sum of squares).  Stage 2 finalises.
+// The apply is fused into the consumer's tile load (conv3 / depthwise conv3), never materialised.
+template <typename T>
+__global__ void instnorm_partial_kernel(const T* __restrict__ x, double* __restrict__ ws, long HW, int C, int pix_per_block) {
+    const int b = blockIdx.y;
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    const long p1 = p0 + pix_per_block < HW ? p0 + pix_per_block : HW;
+    const T* xb = x + (long)b * HW * C;
+    // thread -> (channel, pixel phase): consecutive threads take consecutive channels (coalesced)
+    const bool wide = (int)blockDim.x >= C;            // several pixel phases per channel
+    const int cstride = wide ? C : (int)blockDim.x;
+    const int nphase = wide ? (int)blockDim.x / C : 1;
+    const int phase = wide ? (int)threadIdx.x / C : 0;
+    if (phase >= nphase) return;
+    for (int c = threadIdx.x % cstride; c < C; c += cstride) {
+        double s = 0.0, q = 0.0;
+        float fs = 0.f, fq = 0.f; int run = 0;
+        for (long p = p0 + phase; p < p1; p += nphase) {
+            float v = to_f32(xb[p * C + c]);
+            fs += v; fq += v * v;
+            if (++run == 32) { s += fs; q += fq; fs = fq = 0.f; run = 0; }
+        }
+        s += fs; q += fq;
+        atomicAdd(&ws[((long)b * C + c) * 2 + 0], s);
+        atomicAdd(&ws[((long)b * C + c) * 2 + 1], q);
+    }
+}
+__global__ void instnorm_finalize_kernel(const double* __restrict__ ws, float* __restrict__ mean, float* __restrict__ rstd, long n, double inv_hw, float eps) {
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double m = ws[2 * i] * inv_hw;
+    double var = ws[2 * i + 1] * inv_hw - m * m;
+    if (var < 0) var = 0;
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// InstanceNorm backward.  With xhat = (x - mean) * rstd and g = dL/dxhat:
+//   dx = rstd * (g - mean_hw(g) - xhat * mean_hw(g * xhat))
+// Stage 1 accumulates sum(g), sum(g*xhat) per (b,c) in fp64; stage 2 applies, and optionally folds
+// in the ReLU(+dropout) backward of the producer of x: dx *= (x > 0) * relu_scale.
+template <typename T>
+__global__ void instnorm_bwd_partial_kernel(const T* __restrict__ g, const T* __restrict__ x, const float* __restrict__ mean,
+                                            const float* __restrict__ rstd, double* __restrict__ ws, long HW, int C, int pix_per_block) {
+    const int b = blockIdx.y;
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    const long p1 = p0 + pix_per_block < HW ? p0 + pix_per_block : HW;
+    const long base = (long)b * HW * C;
+    const bool wide = (int)blockDim.x >= C;            // several pixel phases per channel
+    const int cstride = wide ? C : (int)blockDim.x;
+    const int nphase = wide ? (int)blockDim.x / C : 1;
+    const int phase = wide ? (int)threadIdx.x / C : 0;
+    if (phase >= nphase) return;
+    for (int c = threadIdx.x % cstride; c < C; c += cstride) {
+        const float mu = mean[(long)b * C + c], rs = rstd[(long)b * C + c];
+        double s = 0.0, q = 0.0;
+        float fs = 0.f, fq = 0.f; int run = 0;
+        for (long p = p0 + phase; p < p1; p += nphase) {
+            float gv = to_f32(g[base + p * C + c]);
+            float xh = (to_f32(x[base + p * C + c]) - mu) * rs;
+            fs += gv; fq += gv * xh;
+            if (++run == 32) { s += fs; q += fq; fs = fq = 0.f; run = 0; }
+        }
+        s += fs; q += fq;
+        atomicAdd(&ws[((long)b * C + c) * 2 + 0], s);
+        atomicAdd(&ws[((long)b * C + c) * 2 + 1], q);
+    }
+}
+template <typename T>
+__global__ void instnorm_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ x, const float* __restrict__ mean,
+                                          const float* __restrict__ rstd, const double* __restrict__ ws, T* __restrict__ dx, long HW, int C,
+                                          long total, float inv_hw, int relu_mask, float relu_scale) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long b = i / (HW * C);
+        long bc = b * C + c;
+        float mu = mean[bc], rs = rstd[bc];
+        float xv = to_f32(x[i]);
+        float xh = (xv - mu) * rs;
+        float s1 = (float)(ws[2 * bc] * inv_hw), s2 = (float)(ws[2 * bc + 1] * inv_hw);
+        float d = rs * (to_f32(g[i]) - s1 - xh * s2);
+        if (relu_mask) d = xv > 0.f ? d * relu_scale : 0.f;
+        dx[i] = from_f32<T>(d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out = LayerNorm(x + res) * gamma + beta ; one wave per row, d <= 1024, d % 64 == 0 not required.
+// Saves mean and rstd (fp32) for the backward.
+template <typename T, int MAXPER>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ out, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, long M, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[MAXPER];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) {
+        int c = lane + i * 64;
+        v[i] = c < d ? to_f32(x[row * d + c]) + (res ? to_f32(res[row * d + c]) : 0.f) : 0.f;
+        s += v[i];
+    }
+    const float mu = wave_sum(s) / d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) {
+        int c = lane + i * 64;
+        float t = c < d ? v[i] - mu : 0.f;
+        q += t * t;
+    }
+    const float rs = rsqrtf(wave_sum(q) / d + eps);
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) {
+        int c = lane + i * 64;
+        if (c < d) out[row * d + c] = from_f32<T>((v[i] - mu) * rs * gamma[c] + beta[c]);
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// Backward: s = x + res, xhat = (s - mean) * rstd, gh = dy * gamma
+//   ds = rstd * (gh - mean_d(gh) - xhat * mean_d(gh * xhat))      (gradient of BOTH x and res)
+//   dgamma[c] += sum_rows dy * xhat ; dbeta[c] += sum_rows dy     (fp32 atomics, one add per block per column)
+template <typename T, int MAXPER>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ res,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, T* __restrict__ ds, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, long M, int d, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];  // [2][d] per-block column partials
+    float* cg = dyn;
+    float* cb = dyn + d;
+    for (int i = threadIdx.x; i < 2 * d; i += blockDim.x) dyn[i] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    float ag[MAXPER], ab[MAXPER];
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) ag[i] = ab[i] = 0.f;
+    for (long row = r0 + wv; row < r0 + rows_per_block && row < M; row += nw) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[MAXPER], gh[MAXPER];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXPER; ++i) {
+            int c = lane + i * 64;
+            if (c < d) {
+                float sv = to_f32(x[row * d + c]) + (res ? to_f32(res[row * d + c]) : 0.f);
+                float g = to_f32(dy[row * d + c]);
+                xh[i] = (sv - mu) * rs;
+                gh[i] = g * gamma[c];
+                ag[i] += g * xh[i];
+                ab[i] += g;
+                s1 += gh[i]; s2 += gh[i] * xh[i];
+            } else { xh[i] = gh[i] = 0.f; }
+        }
+        s1 = wave_sum(s1) / d; s2 = wave_sum(s2) / d;
+#pragma unroll
+        for (int i = 0; i < MAXPER; ++i) {
+            int c = lane + i * 64;
+            if (c < d) ds[row * d + c] = from_f32<T>(rs * (gh[i] - s1 - xh[i] * s2));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) {
+        int c = lane + i * 64;
+        if (c < d) { atomicAdd(&cg[c], ag[i]); atomicAdd(&cb[c], ab[i]); }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        atomicAdd(&dgamma[c], cg[c]);
+        atomicAdd(&dbeta[c], cb[c]);
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                         \
+    if ((dtype) == OMR_F32) { typedef float T; CALL; }  \
+    else if ((dtype) == OMR_BF16) { typedef bf16 T; CALL; } \
+    else return OMR_ERR_UNSUPPORTED;
+
+extern "C" long omr_instnorm_workspace_bytes(int B, int C) { return (long)B * C * 2 * sizeof(double); }
+
+extern "C" int omr_instnorm_stats(int dtype, const void* x, float* mean, float* rstd, int B, long HW, int C, float eps, void* workspace,
+                                  void* stream) {
+    if (B <= 0 || HW <= 0 || C <= 0 || !workspace) return OMR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, omr_instnorm_workspace_bytes(B, C), s) != hipSuccess) return OMR_ERR_LAUNCH;
+    int ppb = 512;
+    dim3 grid(cdiv(HW, ppb), B);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_partial_kernel<T>), grid, 256, 0, s, (const T*)x, (double*)workspace, HW, C, ppb));
+    long n = (long)B * C;
+    hipLaunchKernelGGL(instnorm_finalize_kernel, cdiv(n, 256), 256, 0, s, (const double*)workspace, mean, rstd, n, 1.0 / (double)HW, eps);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_instnorm_bwd(int dtype, const void* dxhat, const void* x, const float* mean, const float* rstd, void* dx, int B, long HW,
+                                int C, int relu_mask, float relu_scale, void* workspace, void* stream) {
+    if (B <= 0 || HW <= 0 || C <= 0 || !workspace) return OMR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, omr_instnorm_workspace_bytes(B, C), s) != hipSuccess) return OMR_ERR_LAUNCH;
+    int ppb = 512;
+    dim3 grid(cdiv(HW, ppb), B);
+    long total = (long)B * HW * C;
+    long g2 = (total + 255) / 256; if (g2 > 4096) g2 = 4096;
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((instnorm_bwd_partial_kernel<T>), grid, 256, 0, s, (const T*)dxhat, (const T*)x, mean, rstd, (double*)workspace, HW, C, ppb);
+        hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), (int)g2, 256, 0, s, (const T*)dxhat, (const T*)x, mean, rstd, (const double*)workspace,
+                           (T*)dx, HW, C, total, (float)(1.0 / (double)HW), relu_mask, relu_scale);
+    });
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_add_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* out, float* mean,
+                                     float* rstd, long M, int d, float eps, void* stream) {
+    if (M <= 0 || d <= 0 || d > 1024) return OMR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = cdiv(M, 4);
+    DISPATCH_T(dtype, {
+        if (d <= 256) hipLaunchKernelGGL((add_ln_fwd_kernel<T, 4>), grid, 256, 0, s, (const T*)x, (const T*)res, gamma, beta, (T*)out, mean, rstd, M, d, eps);
+        else hipLaunchKernelGGL((add_ln_fwd_kernel<T, 16>), grid, 256, 0, s, (const T*)x, (const T*)res, gamma, beta, (T*)out, mean, rstd, M, d, eps);
+    });
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_add_layernorm_bwd(int dtype, const void* dy, const void* x, const void* res, const float* gamma, const float* mean,
+                                     const float* rstd, void* ds, float* dgamma, float* dbeta, long M, int d, void* stream) {
+    if (M <= 0 || d <= 0 || d > 1024) return OMR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int rpb = 64;
+    int grid = cdiv(M, rpb);
+    size_t shm = 2 * (size_t)d * sizeof(float);
+    DISPATCH_T(dtype, {
+        if (d <= 256) hipLaunchKernelGGL((add_ln_bwd_kernel<T, 4>), grid, 256, shm, s, (const T*)dy, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)ds, dgamma, dbeta, M, d, rpb);
+        else hipLaunchKernelGGL((add_ln_bwd_kernel<T, 16>), grid, 256, shm, s, (const T*)dy, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)ds, dgamma, dbeta, M, d, rpb);
+    });
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}

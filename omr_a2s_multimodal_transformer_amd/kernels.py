@@ -1,0 +1,338 @@
+"""Host-side launchers: tensor-level wrappers over the C ABI (include/omr_hip.h) with shape checks.
+
+No autograd here (see functional.py).  Layout conventions: encoder activations are NHWC tensors
+[B,H,W,C]; 3x3 conv weights are given as their physical [COUT,3,3,CIN] view; token matrices are 2-D
+row-major with unit inner stride (row stride may exceed the width).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import cur_stream, dtype_code, lib, ptr, require_cuda
+
+Tensor = torch.Tensor
+
+
+def _rows2d(t: Tensor) -> Tuple[int, int, int]:
+    assert t.dim() == 2 and t.stride(1) == 1, f"expected a row-major 2-D tensor, got shape {tuple(t.shape)} strides {t.stride()}"
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = False, bias: Optional[Tensor] = None, relu: bool = False,
+         out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None, accumulate: bool = False, split_k: int = 1) -> Tensor:
+    """C[M,N] (+)= act(opA(a) @ opB(b)^T + bias).  a is [M,K] ([K,M] if trans_a); b is [N,K] ([K,N] if trans_b)."""
+    require_cuda(a, b, bias, out)
+    assert a.dtype == b.dtype
+    ar, ac, lda = _rows2d(a)
+    br, bc, ldb = _rows2d(b)
+    M, K = (ac, ar) if trans_a else (ar, ac)
+    N, Kb = (bc, br) if trans_b else (br, bc)
+    assert K == Kb, f"gemm inner dims differ: {K} vs {Kb}"
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device)
+        assert not accumulate and split_k == 1, "accumulating gemm needs an initialised `out`"
+    cr, cc, ldc = _rows2d(out)
+    assert (cr, cc) == (M, N), f"gemm out shape {tuple(out.shape)} != {(M, N)}"
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+    lib().call("omr_gemm", dtype_code(a.dtype), dtype_code(out.dtype), int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb,
+               ptr(out), ldc, ptr(bias), int(relu), int(accumulate), split_k, cur_stream())
+    return out
+
+
+def cast(x: Tensor, dtype: torch.dtype, out: Optional[Tensor] = None) -> Tensor:
+    require_cuda(x)
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x, dtype=dtype)
+    lib().call("omr_cast", ptr(x), dtype_code(x.dtype), ptr(out), dtype_code(dtype), x.numel(), cur_stream())
+    return out
+
+
+def add(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    require_cuda(a, b)
+    assert a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+    if out is None:
+        out = torch.empty_like(a)
+    lib().call("omr_add", dtype_code(a.dtype), ptr(a), ptr(b), ptr(out), a.numel(), cur_stream())
+    return out
+
+
+def relu_bwd(dy: Tensor, y: Tensor, scale: float = 1.0) -> Tensor:
+    require_cuda(dy, y)
+    assert dy.shape == y.shape and dy.dtype == y.dtype and dy.is_contiguous() and y.is_contiguous()
+    dx = torch.empty_like(dy)
+    lib().call("omr_relu_bwd", dtype_code(dy.dtype), ptr(dy), ptr(y), ptr(dx), dy.numel(), float(scale), cur_stream())
+    return dx
+
+
+def dropout(x: Tensor, p: float, seed: int, channel_mode: bool = False) -> Tensor:
+    """Elementwise dropout, or per-(sample, channel) dropout of an NHWC tensor when channel_mode."""
+    require_cuda(x)
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    per_sample = x.numel() // x.shape[0]
+    lib().call("omr_dropout", dtype_code(x.dtype), ptr(x), ptr(out), x.numel(), float(p), int(seed) & (2**64 - 1), int(channel_mode),
+               per_sample, x.shape[-1], cur_stream())
+    return out
+
+
+def embed_pe(tokens: Tensor, table: Tensor, pe: Tensor) -> Tensor:
+    """tokens int64 [B,T]; table [V,d]; pe fp32 [>=T, d] -> [B,T,d]."""
+    require_cuda(tokens, table, pe)
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous() and table.is_contiguous()
+    B, T = tokens.shape
+    V, d = table.shape
+    assert pe.dtype == torch.float32 and pe.is_contiguous() and pe.shape[-1] == d and pe.shape[-2] >= T, "sequence longer than the PE table"
+    out = torch.empty((B, T, d), dtype=table.dtype, device=table.device)
+    lib().call("omr_embed_pe_fwd", dtype_code(table.dtype), ptr(tokens), ptr(table), ptr(pe), ptr(out), B * T, T, d, V, cur_stream())
+    return out
+
+
+def embed_bwd(tokens: Tensor, dout: Tensor, dtable: Tensor, pad_idx: int) -> None:
+    require_cuda(tokens, dout, dtable)
+    assert dtable.dtype == torch.float32 and dout.is_contiguous()
+    V, d = dtable.shape
+    lib().call("omr_embed_bwd", dtype_code(dout.dtype), ptr(tokens), ptr(dout), ptr(dtable), tokens.numel(), d, pad_idx, V, cur_stream())
+
+
+def add_pe2d(x: Tensor, pe_hwc: Tensor) -> Tensor:
+    """x NHWC [B,h,w,C] + pe_hwc fp32 [maxh,maxw,C][:h,:w]."""
+    require_cuda(x, pe_hwc)
+    B, h, w, C = x.shape
+    maxh, maxw, Cp = pe_hwc.shape
+    assert Cp == C and pe_hwc.dtype == torch.float32 and pe_hwc.is_contiguous() and x.is_contiguous()
+    assert h <= maxh and w <= maxw, f"feature map {h}x{w} exceeds the positional-encoding table {maxh}x{maxw}"
+    out = torch.empty_like(x)
+    lib().call("omr_add_pe2d", dtype_code(x.dtype), ptr(x), ptr(pe_hwc), ptr(out), B, h, w, C, maxh, maxw, cur_stream())
+    return out
+
+
+def colsum_into(dy2d: Tensor, db: Tensor) -> None:
+    """db[n] += sum_m dy2d[m, n]  (db fp32)."""
+    require_cuda(dy2d, db)
+    M, N, ld = _rows2d(dy2d)
+    assert db.dtype == torch.float32 and db.numel() == N
+    lib().call("omr_colsum", dtype_code(dy2d.dtype), ptr(dy2d), ptr(db), M, N, ld, cur_stream())
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+              grad_scale: float = 1.0, p_lowp: Optional[Tensor] = None) -> None:
+    require_cuda(p, g, m, v)
+    n = p.numel()
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n
+    if p_lowp is not None:
+        assert p_lowp.dtype == torch.bfloat16 and p_lowp.numel() == n
+    lib().call("omr_adam", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p_lowp), n, step, lr, betas[0], betas[1], eps, grad_scale, cur_stream())
+
+
+def argmax(x: Tensor) -> Tuple[Tensor, Tensor]:
+    require_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 1
+    idx = torch.empty(1, dtype=torch.int64, device=x.device)
+    val = torch.empty(1, dtype=torch.float32, device=x.device)
+    lib().call("omr_argmax", ptr(x), x.numel(), ptr(idx), ptr(val), cur_stream())
+    return idx, val
+
+
+# ------------------------------------------------------------------------------------------------ normalisation
+
+def _in_ws(B: int, C: int, device) -> Tensor:
+    return torch.empty(lib().query("omr_instnorm_workspace_bytes", B, C), dtype=torch.uint8, device=device)
+
+
+def instnorm_stats(x: Tensor, eps: float = 1e-3) -> Tuple[Tensor, Tensor]:
+    """x NHWC -> (mean, rstd) fp32 [B,C]."""
+    require_cuda(x)
+    B, H, W, C = x.shape
+    assert x.is_contiguous()
+    mean = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    lib().call("omr_instnorm_stats", dtype_code(x.dtype), ptr(x), ptr(mean), ptr(rstd), B, H * W, C, eps, ptr(_in_ws(B, C, x.device)), cur_stream())
+    return mean, rstd
+
+
+def instnorm_bwd(dxhat: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, relu_mask: bool, relu_scale: float = 1.0) -> Tensor:
+    require_cuda(dxhat, x)
+    B, H, W, C = x.shape
+    assert dxhat.shape == x.shape and dxhat.is_contiguous() and x.is_contiguous()
+    dx = torch.empty_like(x)
+    lib().call("omr_instnorm_bwd", dtype_code(x.dtype), ptr(dxhat), ptr(x), ptr(mean), ptr(rstd), ptr(dx), B, H * W, C, int(relu_mask),
+               float(relu_scale), ptr(_in_ws(B, C, x.device)), cur_stream())
+    return dx
+
+
+def add_layernorm_fwd(x: Tensor, res: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float = 1e-5):
+    require_cuda(x, res, gamma, beta)
+    d = x.shape[-1]
+    M = x.numel() // d
+    assert x.is_contiguous() and (res is None or (res.is_contiguous() and res.shape == x.shape))
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == d
+    out = torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    lib().call("omr_add_layernorm_fwd", dtype_code(x.dtype), ptr(x), ptr(res), ptr(gamma), ptr(beta), ptr(out), ptr(mean), ptr(rstd), M, d, eps,
+               cur_stream())
+    return out, mean, rstd
+
+
+def add_layernorm_bwd(dy: Tensor, x: Tensor, res: Optional[Tensor], gamma: Tensor, mean: Tensor, rstd: Tensor, dgamma: Tensor, dbeta: Tensor) -> Tensor:
+    require_cuda(dy, x)
+    d = x.shape[-1]
+    M = x.numel() // d
+    assert dy.is_contiguous() and dy.shape == x.shape and dgamma.dtype == torch.float32 and dbeta.dtype == torch.float32
+    ds = torch.empty_like(x)
+    lib().call("omr_add_layernorm_bwd", dtype_code(x.dtype), ptr(dy), ptr(x), ptr(res), ptr(gamma), ptr(mean), ptr(rstd), ptr(ds), ptr(dgamma),
+               ptr(dbeta), M, d, cur_stream())
+    return ds
+
+
+# ------------------------------------------------------------------------------------------------ convolutions
+
+def conv_out_hw(H: int, W: int, stride: Tuple[int, int]) -> Tuple[int, int]:
+    """k=3, pad=1: out = ceil(in / stride)."""
+    return (H + stride[0] - 1) // stride[0], (W + stride[1] - 1) // stride[1]
+
+
+def conv3x3(x: Tensor, w_phys: Tensor, bias: Optional[Tensor], stride=(1, 1), relu: bool = False, in_stats=None, out_mask: Optional[Tensor] = None,
+            mask_scale: float = 1.0, dil=(1, 1), out_hw: Optional[Tuple[int, int]] = None) -> Tensor:
+    """x NHWC [B,H,W,CIN]; w_phys [COUT,3,3,CIN] contiguous; returns NHWC [B,Ho,Wo,COUT]."""
+    require_cuda(x, w_phys, bias, out_mask)
+    B, H, W, CIN = x.shape
+    COUT = w_phys.shape[0]
+    assert x.is_contiguous() and w_phys.is_contiguous() and tuple(w_phys.shape) == (COUT, 3, 3, CIN) and w_phys.dtype == x.dtype
+    if out_hw is None:
+        out_hw = conv_out_hw(H, W, stride)
+    Ho, Wo = out_hw
+    y = torch.empty((B, Ho, Wo, COUT), dtype=x.dtype, device=x.device)
+    mean = rstd = None
+    if in_stats is not None:
+        mean, rstd = in_stats
+        assert tuple(mean.shape) == (B, CIN) and mean.dtype == torch.float32
+    if out_mask is not None:
+        assert out_mask.shape == y.shape and out_mask.is_contiguous() and out_mask.dtype == x.dtype
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == COUT
+    lib().call("omr_conv3x3_fwd", dtype_code(x.dtype), ptr(x), ptr(w_phys), ptr(bias), ptr(y), ptr(mean), ptr(rstd), ptr(out_mask), float(mask_scale),
+               B, H, W, CIN, COUT, stride[0], stride[1], dil[0], dil[1], Ho, Wo, int(relu), cur_stream())
+    return y
+
+
+def conv3x3_weight_flip(w_phys: Tensor) -> Tensor:
+    """[COUT,3,3,CIN] -> [CIN,3,3,COUT] with mirrored taps (weights of the data-gradient conv)."""
+    require_cuda(w_phys)
+    COUT, _, _, CIN = w_phys.shape
+    wd = torch.empty((CIN, 3, 3, COUT), dtype=w_phys.dtype, device=w_phys.device)
+    lib().call("omr_conv3x3_weight_flip", dtype_code(w_phys.dtype), ptr(w_phys), ptr(wd), COUT, CIN, cur_stream())
+    return wd
+
+
+def conv3x3_wgrad(x: Tensor, dy: Tensor, dw_phys: Tensor, stride=(1, 1), in_stats=None) -> None:
+    """dw_phys (fp32 [COUT,3,3,CIN], accumulated in place) += grad."""
+    require_cuda(x, dy, dw_phys)
+    B, H, W, CIN = x.shape
+    _, Ho, Wo, COUT = dy.shape
+    assert (Ho, Wo) == conv_out_hw(H, W, stride) and dy.shape[0] == B
+    assert dw_phys.dtype == torch.float32 and dw_phys.is_contiguous() and tuple(dw_phys.shape) == (COUT, 3, 3, CIN)
+    assert x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype
+    mean, rstd = in_stats if in_stats is not None else (None, None)
+    lib().call("omr_conv3x3_wgrad", dtype_code(x.dtype), ptr(x), ptr(dy), ptr(dw_phys), ptr(mean), ptr(rstd), B, H, W, CIN, COUT, stride[0], stride[1],
+               Ho, Wo, cur_stream())
+
+
+def dwconv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor], in_stats=None, out_mask: Optional[Tensor] = None, mask_scale: float = 1.0,
+              flip: bool = False) -> Tensor:
+    """Depthwise 3x3 on NHWC; w is [C,9] (= [C,1,3,3] storage)."""
+    require_cuda(x, w, bias, out_mask)
+    B, H, W, C = x.shape
+    assert x.is_contiguous() and w.is_contiguous() and w.numel() == C * 9 and w.dtype == x.dtype
+    y = torch.empty_like(x)
+    mean, rstd = in_stats if in_stats is not None else (None, None)
+    if out_mask is not None:
+        assert out_mask.shape == x.shape and out_mask.is_contiguous()
+    lib().call("omr_dwconv3x3", dtype_code(x.dtype), ptr(x), ptr(w), ptr(bias), ptr(y), ptr(mean), ptr(rstd), ptr(out_mask), float(mask_scale), B, H, W,
+               C, int(flip), cur_stream())
+    return y
+
+
+def dwconv3x3_wgrad(x: Tensor, dy: Tensor, dw: Tensor, db: Optional[Tensor], in_stats=None) -> None:
+    require_cuda(x, dy, dw, db)
+    B, H, W, C = x.shape
+    assert dy.shape == x.shape and dw.dtype == torch.float32 and dw.numel() == C * 9 and x.is_contiguous() and dy.is_contiguous()
+    mean, rstd = in_stats if in_stats is not None else (None, None)
+    lib().call("omr_dwconv3x3_wgrad", dtype_code(x.dtype), ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(mean), ptr(rstd), B, H, W, C, cur_stream())
+
+
+# ------------------------------------------------------------------------------------------------ attention
+
+def _bts(t: Tensor) -> Tuple[int, int]:
+    assert t.dim() == 3 and t.stride(2) == 1, f"expected [B,rows,cols] with unit inner stride, got {tuple(t.shape)} / {t.stride()}"
+    return t.stride(1), t.stride(0)
+
+
+def attn_fwd(q: Tensor, k: Tensor, v: Tensor, nhead: int, *, causal: bool = False, window: int = -1, key_bias: Optional[Tensor] = None,
+             blk_lq: Optional[Tensor] = None, blk_lkv: Optional[Tensor] = None, dropout_p: float = 0.0, seed: int = 0):
+    """q [B,T,d], k/v [B,S,d] (may be strided views of packed projections) -> (o [B,T,d], lse [B,H,T])."""
+    require_cuda(q, k, v, key_bias, blk_lq, blk_lkv)
+    B, T, d = q.shape
+    S = k.shape[1]
+    assert k.shape == (B, S, d) and v.shape == (B, S, d) and d % nhead == 0 and q.dtype == k.dtype == v.dtype
+    hd = d // nhead
+    o = torch.empty((B, T, d), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, nhead, T), dtype=torch.float32, device=q.device)
+    if key_bias is not None:
+        assert key_bias.dtype == torch.float32 and tuple(key_bias.shape) == (B, S) and key_bias.is_contiguous()
+    for t in (blk_lq, blk_lkv):
+        if t is not None:
+            assert t.dtype == torch.int32 and t.numel() == B and t.is_contiguous()
+    (ldq, bsq), (ldk, bsk), (ldv, bsv), (ldo, bso) = _bts(q), _bts(k), _bts(v), _bts(o)
+    lib().call("omr_attn_fwd", dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, nhead, T, S, hd,
+               int(causal), int(window), ptr(key_bias), ptr(blk_lq), ptr(blk_lkv), float(dropout_p), int(seed) & (2**64 - 1), cur_stream())
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, nhead: int, *, causal=False, window=-1, key_bias=None, blk_lq=None, blk_lkv=None,
+             dropout_p: float = 0.0, seed: int = 0) -> None:
+    """Writes dq [B,T,d], dk/dv [B,S,d] (views allowed, unit inner stride)."""
+    require_cuda(q, k, v, o, dout, dq, dk, dv)
+    B, T, d = q.shape
+    S = k.shape[1]
+    hd = d // nhead
+    delta = torch.empty((B, nhead, T), dtype=torch.float32, device=q.device)
+    assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape and dout.shape == o.shape
+    (ldq, bsq), (ldk, bsk), (ldv, bsv), (ldo, bso), (lddo, bsdo) = _bts(q), _bts(k), _bts(v), _bts(o), _bts(dout)
+    (lddq, bsdq), (lddk, bsdk), (lddv, bsdv) = _bts(dq), _bts(dk), _bts(dv)
+    lib().call("omr_attn_bwd", dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ldq, ldk,
+               ldv, ldo, lddo, lddq, lddk, lddv, bsq, bsk, bsv, bso, bsdo, bsdq, bsdk, bsdv, B, nhead, T, S, hd, int(causal), int(window),
+               ptr(key_bias), ptr(blk_lq), ptr(blk_lkv), float(dropout_p), int(seed) & (2**64 - 1), cur_stream())
+
+
+# ------------------------------------------------------------------------------------------------ loss
+
+def ce_fwd(logits2d: Tensor, target: Tensor, V: int, pad_idx: int):
+    """logits2d [M, ldv>=V]; target int64 [M] -> (loss fp32 [1], lse [M], acc2 fp64 [2])."""
+    require_cuda(logits2d, target)
+    M, cols, ldv = _rows2d(logits2d)
+    assert cols >= V and target.numel() == M and target.dtype == torch.int64 and target.is_contiguous()
+    lse = torch.empty(M, dtype=torch.float32, device=logits2d.device)
+    acc2 = torch.empty(2, dtype=torch.float64, device=logits2d.device)
+    loss = torch.empty(1, dtype=torch.float32, device=logits2d.device)
+    lib().call("omr_ce_fwd", dtype_code(logits2d.dtype), ptr(logits2d), ptr(target), ptr(lse), ptr(acc2), ptr(loss), M, V, ldv, pad_idx, cur_stream())
+    return loss, lse, acc2
+
+
+def ce_bwd(logits2d: Tensor, target: Tensor, lse: Tensor, acc2: Tensor, V: int, pad_idx: int, grad_scale: float = 1.0) -> Tensor:
+    require_cuda(logits2d, target)
+    M, cols, ldv = _rows2d(logits2d)
+    dl = torch.empty((M, ldv), dtype=logits2d.dtype, device=logits2d.device)
+    lib().call("omr_ce_bwd", dtype_code(logits2d.dtype), ptr(logits2d), ptr(target), ptr(lse), ptr(acc2), ptr(dl), M, V, ldv, pad_idx, float(grad_scale),
+               cur_stream())
+    return dl[:, :cols]
+
+
+def round_up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m

@@ -1,0 +1,396 @@
+"""Per-kernel parity: each C-ABI entry point (through the ctypes binding) vs torch CPU fp32 / the oracle.
+fp32 runs are held to ~1e-4 (exact-f32 MFMA chain, different summation order); bf16 runs to bf16 rounding."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R  # noqa: E402
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def K():
+    from omr_a2s_multimodal_transformer_amd import kernels
+    return kernels
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g) * (hi - lo) + lo
+
+
+def q(t, dtype):
+    """Quantise a CPU fp32 tensor to the test dtype and back (the reference sees what the kernel sees)."""
+    return t.to(dtype).float()
+
+
+def tol(dtype, scale=1.0):
+    return dict(rtol=2e-4, atol=2e-4 * scale) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2 * scale)
+
+
+def check(got, ref, dtype, scale=1.0, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    torch.testing.assert_close(got, ref, **tol(dtype, scale), msg=lambda m: f"{what}: {m}")
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K_", [(200, 100, 72), (128, 128, 32), (257, 300, 264), (64, 6997, 256)])
+def test_gemm_nt_bias_relu(dtype, M, N, K_):
+    a, b, bias = q(rnd((M, K_), 1), dtype), q(rnd((N, K_), 2), dtype), rnd((N,), 3)
+    ref = F.relu(a @ b.t() + bias)
+    out = K().gemm(a.to(dev(), dtype), b.to(dev(), dtype), bias=bias.to(dev()), relu=True)
+    check(out, ref, dtype, scale=math.sqrt(K_) / 4, what="gemm NT")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_trans_b(dtype):
+    M, N, K_ = 150, 96, 200
+    a, b = q(rnd((M, K_), 4), dtype), q(rnd((K_, N), 5), dtype)
+    out = K().gemm(a.to(dev(), dtype), b.to(dev(), dtype), trans_b=True)
+    check(out, a @ b, dtype, scale=4, what="gemm transB")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("split", [1, 4])
+def test_gemm_tn_accumulate(dtype, split):
+    Mred, N, K_ = 700, 72, 136  # dW[N,K] = dY[Mred,N]^T X[Mred,K]
+    dy, x = q(rnd((Mred, N), 6), dtype), q(rnd((Mred, K_), 7), dtype)
+    init = rnd((N, K_), 8)
+    out = init.to(dev()).clone()
+    K().gemm(dy.to(dev(), dtype), x.to(dev(), dtype), trans_a=True, trans_b=True, out=out, accumulate=True, split_k=split)
+    check(out, init + dy.t() @ x, dtype, scale=8, what="gemm TN")
+
+
+def test_gemm_rejects_unaligned():
+    a = torch.zeros((8, 30), device=dev())
+    with pytest.raises(RuntimeError):
+        K().gemm(a, a)
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_add_relu_bwd(dtype):
+    a, b = q(rnd((3, 1001), 9), dtype), q(rnd((3, 1001), 10), dtype)
+    check(K().add(a.to(dev(), dtype), b.to(dev(), dtype)), a + b, dtype, what="add")
+    check(K().relu_bwd(a.to(dev(), dtype), b.to(dev(), dtype), 2.0), a * (b > 0) * 2.0, dtype, what="relu_bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_pe_fwd_bwd(dtype):
+    V, d, B, T = 50, 64, 3, 7
+    table = q(rnd((V, d), 11), dtype)
+    table[0] = 0
+    pe = R.pe1d_table(12, d)[0]
+    g = torch.Generator().manual_seed(1)
+    tok = torch.randint(0, V, (B, T), generator=g)
+    tok[1, 4:] = 0
+    out = K().embed_pe(tok.to(dev()), table.to(dev(), dtype), pe.to(dev()))
+    check(out, table[tok] + pe[:T], dtype, what="embed+pe")
+    dout = q(rnd((B, T, d), 12), dtype)
+    dtab = torch.zeros((V, d), device=dev())
+    K().embed_bwd(tok.to(dev()), dout.to(dev(), dtype), dtab, 0)
+    ref = torch.zeros(V, d)
+    ref.index_add_(0, tok.flatten(), dout.reshape(-1, d))
+    ref[0] = 0
+    check(dtab, ref, torch.float32, what="embed bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_add_pe2d(dtype):
+    pe = R.pe2d_table(64, 5, 9)  # [1,C,h,w]
+    x = q(rnd((2, 3, 7, 64), 13), dtype)  # NHWC
+    out = K().add_pe2d(x.to(dev(), dtype), pe[0].permute(1, 2, 0).contiguous().to(dev()))
+    ref = x + pe[0, :, :3, :7].permute(1, 2, 0)
+    check(out, ref, dtype, what="pe2d")
+    with pytest.raises(AssertionError):
+        K().add_pe2d(torch.zeros((1, 6, 7, 64), device=dev()), pe[0].permute(1, 2, 0).contiguous().to(dev()))
+
+
+def test_colsum_adam_argmax():
+    x = rnd((1000, 70), 14)
+    db = torch.zeros(70, device=dev())
+    K().colsum_into(x.to(dev()), db)
+    check(db, x.sum(0), torch.float32, scale=10, what="colsum")
+    p, g = rnd((5000,), 15), rnd((5000,), 16)
+    pr, m, v = p.clone(), torch.zeros(5000), torch.zeros(5000)
+    pg, mg, vg = p.to(dev()), torch.zeros(5000, device=dev()), torch.zeros(5000, device=dev())
+    lp = torch.empty(5000, dtype=torch.bfloat16, device=dev())
+    for step in (1, 2, 3):
+        R.adam_step([pr], [g], [m], [v], step, lr=1e-3)
+        K().adam_step(pg, g.to(dev()), mg, vg, step, 1e-3, p_lowp=lp)
+    torch.testing.assert_close(pg.cpu(), pr, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(lp.float().cpu(), pr.bfloat16().float(), rtol=1e-2, atol=1e-3)
+    z = rnd((6997,), 17)
+    z[4000] = z[123] = 5.0
+    idx, val = K().argmax(z.to(dev()))
+    assert int(idx) == 123 and float(val) == 5.0
+
+
+def test_dropout_statistics():
+    x = torch.ones((4, 16, 32, 8), device=dev())
+    y = K().dropout(x, 0.5, seed=7)
+    keep = (y > 0).float().mean().item()
+    assert abs(keep - 0.5) < 0.02 and torch.allclose(y[y > 0], torch.tensor(2.0, device=dev()))
+    y2 = K().dropout(x, 0.25, seed=9, channel_mode=True)
+    per = (y2 > 0).float().mean(dim=(1, 2))  # [B, C]: whole channels kept or dropped
+    assert set(per.flatten().tolist()) <= {0.0, 1.0}
+    assert torch.equal(K().dropout(x, 0.5, seed=7), y)
+
+
+# ------------------------------------------------------------------------------------------------ norms
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [16, 128, 320])
+def test_instnorm_stats_and_bwd(dtype, C):
+    B, H, W = 2, 9, 37
+    x = q(F.relu(rnd((B, H, W, C), 18) + 0.3), dtype)  # NHWC
+    xn = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    y = R.instance_norm(xn)
+    mean, rstd = K().instnorm_stats(x.to(dev(), dtype))
+    check(mean, xn.detach().mean((2, 3)), torch.float32, what="in mean")
+    check(rstd, 1 / torch.sqrt(xn.detach().var((2, 3), unbiased=False) + 1e-3), torch.float32, scale=5, what="in rstd")
+    g = q(rnd((B, H, W, C), 19), dtype)
+    y.backward(g.permute(0, 3, 1, 2))
+    dx = K().instnorm_bwd(g.to(dev(), dtype), x.to(dev(), dtype), mean, rstd, relu_mask=False)
+    check(dx, xn.grad.permute(0, 2, 3, 1), dtype, scale=3, what="in bwd")
+    dxm = K().instnorm_bwd(g.to(dev(), dtype), x.to(dev(), dtype), mean, rstd, relu_mask=True, relu_scale=2.0)
+    check(dxm, (xn.grad * (xn.detach() > 0) * 2.0).permute(0, 2, 3, 1), dtype, scale=6, what="in bwd masked")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("d", [128, 256])
+def test_add_layernorm(dtype, d):
+    M = 70
+    x, res = q(rnd((M, d), 20), dtype), q(rnd((M, d), 21), dtype)
+    gamma, beta = rnd((d,), 22) + 1.5, rnd((d,), 23)
+    xs = [t.clone().requires_grad_(True) for t in (x, res, gamma, beta)]
+    ref = R.layer_norm(xs[0] + xs[1], xs[2], xs[3])
+    out, mean, rstd = K().add_layernorm_fwd(x.to(dev(), dtype), res.to(dev(), dtype), gamma.to(dev()), beta.to(dev()))
+    check(out, ref, dtype, scale=3, what="ln fwd")
+    g = q(rnd((M, d), 24), dtype)
+    ref.backward(g)
+    dg, db = torch.zeros(d, device=dev()), torch.zeros(d, device=dev())
+    ds = K().add_layernorm_bwd(g.to(dev(), dtype), x.to(dev(), dtype), res.to(dev(), dtype), gamma.to(dev()), mean, rstd, dg, db)
+    check(ds, xs[0].grad, dtype, scale=4, what="ln ds")
+    check(dg, xs[2].grad, dtype, scale=8, what="ln dgamma")
+    check(db, xs[3].grad, dtype, scale=8, what="ln dbeta")
+
+
+# ------------------------------------------------------------------------------------------------ convolutions
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+CONV_CASES = [  # CIN, COUT, stride, H, W
+    (1, 16, (1, 1), 13, 45), (16, 16, (1, 1), 11, 37), (16, 32, (1, 1), 9, 33), (32, 32, (2, 2), 13, 41), (64, 64, (2, 2), 12, 70),
+    (64, 128, (1, 1), 7, 35), (128, 128, (2, 1), 9, 34), (128, 128, (2, 2), 8, 36),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,stride,H,W", CONV_CASES)
+def test_conv3x3_fwd_bwd(dtype, cin, cout, stride, H, W):
+    B = 2
+    x = q(rnd((B, cin, H, W), 30), dtype).requires_grad_(True)
+    w = q(rnd((cout, cin, 3, 3), 31) / math.sqrt(cin * 9) * 2, dtype).requires_grad_(True)
+    bias = rnd((cout,), 32).requires_grad_(True)
+    y = F.relu(F.conv2d(x, w, bias, stride=stride, padding=1))
+    k = K()
+    xg = nhwc(x.detach()).to(dev(), dtype)
+    wg = w.detach().permute(0, 2, 3, 1).contiguous().to(dev(), dtype)
+    yg = k.conv3x3(xg, wg, bias.detach().to(dev()), stride=stride, relu=True)
+    check(yg, nhwc(y), dtype, what="conv fwd")
+    # backward: g = dL/d(pre-activation) (the ReLU mask is applied by the caller protocol)
+    g = q(rnd(tuple(y.shape), 33), dtype)
+    pre = F.conv2d(x, w, bias, stride=stride, padding=1)
+    pre.backward(g)
+    gg = nhwc(g).to(dev(), dtype)
+    dw = torch.zeros((cout, 3, 3, cin), device=dev())
+    k.conv3x3_wgrad(xg, gg, dw, stride=stride)
+    check(dw, w.grad.permute(0, 2, 3, 1), dtype, scale=math.sqrt(B * H * W) / 2, what="conv wgrad")
+    if cin > 1:
+        wd = k.conv3x3_weight_flip(wg)
+        dx = k.conv3x3(gg, wd, None, stride=(1, 1), dil=stride, out_hw=(H, W))
+        check(dx, nhwc(x.grad), dtype, scale=2, what="conv dgrad")
+        dxm = k.conv3x3(gg, wd, None, stride=(1, 1), dil=stride, out_hw=(H, W), out_mask=xg, mask_scale=2.0)
+        check(dxm, nhwc(x.grad * (x.detach() > 0) * 2.0), dtype, scale=4, what="conv dgrad masked")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_fused_instnorm(dtype):
+    B, C, H, W = 2, 32, 10, 40
+    x = q(F.relu(rnd((B, C, H, W), 34)), dtype).requires_grad_(True)
+    w = q(rnd((C, C, 3, 3), 35) / 12, dtype).requires_grad_(True)
+    xh = R.instance_norm(x)
+    xh.retain_grad()
+    pre = F.conv2d(xh, w, None, stride=(2, 2), padding=1)
+    k = K()
+    xg = nhwc(x.detach()).to(dev(), dtype)
+    wg = w.detach().permute(0, 2, 3, 1).contiguous().to(dev(), dtype)
+    stats = k.instnorm_stats(xg)
+    yg = k.conv3x3(xg, wg, None, stride=(2, 2), in_stats=stats)
+    check(yg, nhwc(pre), dtype, scale=2, what="norm+conv fwd")
+    g = q(rnd(tuple(pre.shape), 36), dtype)
+    pre.backward(g)
+    dw = torch.zeros((C, 3, 3, C), device=dev())
+    k.conv3x3_wgrad(xg, nhwc(g).to(dev(), dtype), dw, stride=(2, 2), in_stats=stats)
+    check(dw, w.grad.permute(0, 2, 3, 1), dtype, scale=8, what="norm+conv wgrad")
+    dxh = k.conv3x3(nhwc(g).to(dev(), dtype), k.conv3x3_weight_flip(wg), None, dil=(2, 2), out_hw=(H, W))
+    check(dxh, nhwc(xh.grad), dtype, scale=2, what="norm+conv dgrad")
+    dx = k.instnorm_bwd(dxh, xg, stats[0], stats[1], relu_mask=False)
+    check(dx, nhwc(x.grad), dtype, scale=8, what="norm bwd chain")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [128, 256])
+def test_dwconv3x3(dtype, C):
+    B, H, W = 2, 6, 19
+    x = q(rnd((B, C, H, W), 37), dtype).requires_grad_(True)
+    w = q(rnd((C, 1, 3, 3), 38) / 3, dtype).requires_grad_(True)
+    bias = rnd((C,), 39).requires_grad_(True)
+    y = F.conv2d(x, w, bias, padding=1, groups=C)
+    k = K()
+    xg, wg = nhwc(x.detach()).to(dev(), dtype), w.detach().reshape(C, 9).to(dev(), dtype)
+    check(k.dwconv3x3(xg, wg, bias.detach().to(dev())), nhwc(y), dtype, what="dw fwd")
+    g = q(rnd((B, C, H, W), 40), dtype)
+    y.backward(g)
+    gg = nhwc(g).to(dev(), dtype)
+    check(k.dwconv3x3(gg, wg, None, flip=True), nhwc(x.grad), dtype, what="dw dgrad")
+    dw, db = torch.zeros((C, 9), device=dev()), torch.zeros(C, device=dev())
+    k.dwconv3x3_wgrad(xg, gg, dw, db)
+    check(dw, w.grad.reshape(C, 9), dtype, scale=6, what="dw wgrad")
+    check(db, bias.grad, dtype, scale=6, what="dw bgrad")
+    # fused InstanceNorm on the input
+    x2 = q(F.relu(rnd((B, C, H, W), 41)), dtype)
+    stats = k.instnorm_stats(nhwc(x2).to(dev(), dtype))
+    ref = F.conv2d(R.instance_norm(x2), w.detach(), bias.detach(), padding=1, groups=C)
+    check(k.dwconv3x3(nhwc(x2).to(dev(), dtype), wg, bias.detach().to(dev()), in_stats=stats), nhwc(ref), dtype, scale=2, what="dw norm fwd")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+
+def ref_attention(qh, kh, vh, nhead, bias):
+    """[B,T,d] x [B,S,d]: softmax(QK^T/sqrt(hd) + bias[B,H,T,S]) V, heads = contiguous channel slices."""
+    B, T, d = qh.shape
+    S = kh.shape[1]
+    hd = d // nhead
+    qq = qh.view(B, T, nhead, hd).transpose(1, 2)
+    kk = kh.view(B, S, nhead, hd).transpose(1, 2)
+    vv = vh.view(B, S, nhead, hd).transpose(1, 2)
+    s = qq @ kk.transpose(-1, -2) / math.sqrt(hd)
+    if bias is not None:
+        s = s + bias
+    return (torch.softmax(s, -1) @ vv).transpose(1, 2).reshape(B, T, d)
+
+
+ATTN_CASES = [  # name, T, S, d, nhead, causal, window, key_bias kind, blk
+    ("self_causal_pad", 70, 70, 256, 4, True, -1, "plus1", False),
+    ("self_window", 150, 150, 256, 4, True, 20, None, False),
+    ("self_window_ge_T", 33, 33, 128, 4, True, 100, "plus1", False),
+    ("cross_bool", 40, 200, 256, 4, False, -1, "neginf", False),
+    ("cross_plus1", 129, 77, 128, 4, False, -1, "plus1", False),
+    ("cross_blk_quirk", 50, 90, 256, 4, False, -1, None, True),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name,T,S,d,nhead,causal,window,kb,blk", ATTN_CASES)
+def test_attention_fwd_bwd(dtype, name, T, S, d, nhead, causal, window, kb, blk):
+    B = 3
+    packed = T == S and causal
+    qv, kv, vv = (q(rnd((B, n, d), 50 + i), dtype).requires_grad_(True) for i, n in enumerate((T, S, S)))
+    bias = torch.zeros(B, nhead, T, S)
+    key_bias = None
+    lens = torch.tensor([S, (2 * S) // 3, S // 3])
+    if kb is not None:
+        key_bias = torch.zeros(B, S)
+        for i, l in enumerate(lens.tolist()):
+            key_bias[i, l:] = 1.0 if kb == "plus1" else float("-inf")
+        bias = bias + key_bias.view(B, 1, 1, S)
+    if causal:
+        bias = bias + R.tgt_attn_mask(T, window).view(1, 1, T, T)
+    lq = lkv = None
+    if blk:
+        lq = torch.tensor([T, T // 2, T // 4], dtype=torch.int32)
+        lkv = torch.tensor([S, S // 2, S // 5], dtype=torch.int32)
+        m = torch.zeros(B, T, S)
+        for i in range(B):
+            m[i, int(lq[i]):, int(lkv[i]):] = float("-inf")
+        bias = bias + m[torch.arange(B * nhead) % B].view(B, nhead, T, S)
+    ref = ref_attention(qv, kv, vv, nhead, bias)
+    g = q(rnd((B, T, d), 60), dtype)
+    ref.backward(g)
+    k = K()
+    if packed:  # q|k|v packed [B,T,3d] views, as the decoder's self-attention uses them
+        qkv = torch.cat([qv, kv, vv], dim=-1).detach().to(dev(), dtype)
+        qg, kg, vg = qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:]
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = dqkv[:, :, :d], dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:]
+    else:
+        qg, kg, vg = (t.detach().to(dev(), dtype) for t in (qv, kv, vv))
+        dq, dk, dv = torch.empty_like(qg), torch.empty_like(kg), torch.empty_like(vg)
+    kw = dict(causal=causal, window=window, key_bias=None if key_bias is None else key_bias.to(dev()),
+              blk_lq=None if lq is None else lq.to(dev()), blk_lkv=None if lkv is None else lkv.to(dev()))
+    o, lse = k.attn_fwd(qg, kg, vg, nhead, **kw)
+    check(o, ref, dtype, what=f"attn fwd {name}")
+    k.attn_bwd(qg, kg, vg, o, g.to(dev(), dtype), lse, dq, dk, dv, nhead, **kw)
+    check(dq, qv.grad, dtype, what=f"attn dq {name}")
+    check(dk, kv.grad, dtype, what=f"attn dk {name}")
+    check(dv, vv.grad, dtype, what=f"attn dv {name}")
+
+
+def test_attention_dropout_consistency():
+    """Forward and backward regenerate the same mask: check dV against a reference built from the
+    kernel's own dropped probabilities (recovered with V = identity)."""
+    B, T, S, d, nhead = 1, 64, 64, 64, 1
+    k = K()
+    qg = rnd((B, T, d), 70).to(dev())
+    kg = rnd((B, S, d), 71).to(dev())
+    eye = torch.eye(S, d, device=dev()).view(1, S, d).contiguous()
+    pd, lse = k.attn_fwd(qg, kg, eye, nhead, dropout_p=0.3, seed=5)  # = dropped, rescaled probabilities
+    p_full, _ = k.attn_fwd(qg, kg, eye, nhead)
+    kept = pd > 0
+    assert abs(kept.float().mean().item() - 0.7) < 0.05
+    torch.testing.assert_close(pd[kept], (p_full / 0.7)[kept], rtol=1e-4, atol=1e-6)
+    vg = rnd((B, S, d), 72).to(dev())
+    o, lse = k.attn_fwd(qg, kg, vg, nhead, dropout_p=0.3, seed=5)
+    torch.testing.assert_close(o, pd @ vg, rtol=1e-3, atol=1e-4)
+    g = rnd((B, T, d), 73).to(dev())
+    dq, dk, dv = torch.empty_like(qg), torch.empty_like(kg), torch.empty_like(vg)
+    k.attn_bwd(qg, kg, vg, o, g, lse, dq, dk, dv, nhead, dropout_p=0.3, seed=5)
+    torch.testing.assert_close(dv[0], pd[0].t() @ g[0], rtol=1e-3, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ loss
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cross_entropy(dtype):
+    M, V = 37, 6997
+    Vp = K().round_up(V, 8)
+    logits = q(rnd((M, V), 80, -4, 4), dtype).requires_grad_(True)
+    g = torch.Generator().manual_seed(2)
+    tgt = torch.randint(1, V, (M,), generator=g)
+    tgt[5:9] = 0
+    ref = F.cross_entropy(logits, tgt, ignore_index=0)
+    ref.backward()
+    buf = torch.zeros((M, Vp), dtype=dtype, device=dev())
+    buf[:, :V] = logits.detach().to(dev(), dtype)
+    loss, lse, acc2 = K().ce_fwd(buf[:, :V], tgt.to(dev()), V, 0)
+    torch.testing.assert_close(loss.cpu()[0], ref.detach(), rtol=1e-4 if dtype == torch.float32 else 1e-2, atol=1e-4)
+    dl = K().ce_bwd(buf[:, :V], tgt.to(dev()), lse, acc2, V, 0)
+    check(dl, logits.grad, dtype, scale=0.01, what="ce bwd")
