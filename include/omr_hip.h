@@ -103,8 +103,9 @@ int omr_attn_bwd(int dtype, const void* q, const void* k, const void* v, const v
 /* CrossEntropyLoss(ignore_index=pad) (model.py:109,166) on row-major logits [M][ldv]; acc2 = {sum, count} (fp64). */
 int omr_ce_fwd(int dtype, const void* logits, const long* target, float* lse, double* acc2, float* loss_out, long M, int V, long ldv,
                int pad_idx, void* stream);
+/* grad_out (nullable): device pointer to the upstream scalar gradient dL/dloss (multiplies grad_scale). */
 int omr_ce_bwd(int dtype, const void* logits, const long* target, const float* lse, const double* acc2, void* dlogits, long M, int V,
-               long ldv, int pad_idx, float grad_scale, void* stream);
+               long ldv, int pad_idx, float grad_scale, const float* grad_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -43,12 +43,12 @@ __global__ void ce_finalize_kernel(const double* __restrict__ acc, float* __rest
 template <typename T>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logits, const long* __restrict__ target, const float* __restrict__ lse,
                                                      const double* __restrict__ acc, T* __restrict__ dlogits, int V, long ldv, int pad_idx,
-                                                     float gscale) {
+                                                     float gscale, const float* __restrict__ grad_out) {
     const long row = blockIdx.x;
     const long t = target[row];
     const bool live = (t != pad_idx && t >= 0 && t < V);
     const float l = lse[row];
-    const float sc = live ? gscale / (float)acc[1] : 0.f;
+    const float sc = live ? gscale * (grad_out ? grad_out[0] : 1.f) / (float)acc[1] : 0.f;
     const T* lr = logits + row * ldv;
     T* dr = dlogits + row * ldv;
     for (int v = threadIdx.x; v < ldv; v += 256) {
@@ -74,11 +74,11 @@ extern "C" int omr_ce_fwd(int dtype, const void* logits, const long* target, flo
 }
 
 extern "C" int omr_ce_bwd(int dtype, const void* logits, const long* target, const float* lse, const double* acc2, void* dlogits, long M, int V,
-                          long ldv, int pad_idx, float grad_scale, void* stream) {
+                          long ldv, int pad_idx, float grad_scale, const float* grad_out, void* stream) {
     if (M <= 0 || V <= 0 || ldv < V) return OMR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == OMR_F32) hipLaunchKernelGGL((ce_bwd_kernel<float>), (int)M, 256, 0, s, (const float*)logits, target, lse, acc2, (float*)dlogits, V, ldv, pad_idx, grad_scale);
-    else if (dtype == OMR_BF16) hipLaunchKernelGGL((ce_bwd_kernel<bf16>), (int)M, 256, 0, s, (const bf16*)logits, target, lse, acc2, (bf16*)dlogits, V, ldv, pad_idx, grad_scale);
+    if (dtype == OMR_F32) hipLaunchKernelGGL((ce_bwd_kernel<float>), (int)M, 256, 0, s, (const float*)logits, target, lse, acc2, (float*)dlogits, V, ldv, pad_idx, grad_scale, grad_out);
+    else if (dtype == OMR_BF16) hipLaunchKernelGGL((ce_bwd_kernel<bf16>), (int)M, 256, 0, s, (const bf16*)logits, target, lse, acc2, (bf16*)dlogits, V, ldv, pad_idx, grad_scale, grad_out);
     else return OMR_ERR_UNSUPPORTED;
     OMR_CHECK_LAUNCH();
     return OMR_OK;

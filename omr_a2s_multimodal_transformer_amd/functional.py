@@ -1,0 +1,307 @@
+"""torch.autograd plumbing over the HIP kernels (kernels.py).
+
+Every Function's forward AND backward run hand-written gfx950 kernels through the C ABI; torch only
+provides tensors, views and the autograd graph.  Parameter gradients are accumulated by the kernels
+straight into the model's flat fp32 gradient buffer (``param.omr_grad`` views, see params.py), so the
+Functions return ``None`` for parameters: there is no per-parameter gradient copy, the optimizer and
+the gradient all-reduce work on one flat buffer.
+
+Gradient protocol inside the encoder blocks: a layer whose output goes through ReLU (+dropout) can
+leave the activation-function backward to its consumer (``mask_input=True`` there), which applies
+``(x > 0) * scale`` in the epilogue of its data-gradient kernel -- x being exactly the saved
+post-activation tensor, no mask is ever stored or regenerated.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+
+Tensor = torch.Tensor
+
+
+def wt(p: Tensor, dtype: torch.dtype) -> Tensor:
+    """Physical compute view of a parameter in the compute dtype (params.py attaches them)."""
+    if dtype == torch.float32:
+        return p.omr_phys
+    lp = p.omr_lowp
+    if lp is None:
+        raise RuntimeError("bf16 compute copy missing: call model.flatten_parameters(compute_dtype=torch.bfloat16)")
+    return lp
+
+
+def split_k_for(m_red: int) -> int:
+    return max(1, min(128, (m_red + 255) // 256))
+
+
+# ------------------------------------------------------------------------------------------------ encoder
+
+class Conv3x3Fn(Function):
+    """[InstanceNorm ->] Conv2d(3x3, pad 1, stride) -> +bias [-> ReLU] on NHWC  (ConvBlock, encoder.py:159-181)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, relu, use_norm, mask_own, mask_input, in_scale):
+        dt = x.dtype
+        stats = K.instnorm_stats(x) if use_norm else None
+        y = K.conv3x3(x, wt(weight, dt), bias.omr_phys, stride=stride, relu=relu, in_stats=stats)
+        ctx.cfg = (stride, relu, mask_own, mask_input, in_scale)
+        ctx.weight, ctx.bias, ctx.stats = weight, bias, stats
+        ctx.save_for_backward(x, y if (relu and mask_own) else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        stride, relu, mask_own, mask_input, in_scale = ctx.cfg
+        x, y = ctx.saved_tensors
+        weight, bias, stats = ctx.weight, ctx.bias, ctx.stats
+        g = gy.contiguous()
+        if relu and mask_own:
+            g = K.relu_bwd(g, y)
+        cout = g.shape[-1]
+        K.colsum_into(g.view(-1, cout), bias.omr_grad)
+        K.conv3x3_wgrad(x, g, weight.omr_grad, stride=stride, in_stats=stats)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wd = K.conv3x3_weight_flip(wt(weight, x.dtype))
+            H, W = x.shape[1], x.shape[2]
+            if stats is None:
+                dx = K.conv3x3(g, wd, None, stride=(1, 1), dil=stride, out_hw=(H, W), out_mask=x if mask_input else None, mask_scale=in_scale)
+            else:
+                dxh = K.conv3x3(g, wd, None, stride=(1, 1), dil=stride, out_hw=(H, W))
+                dx = K.instnorm_bwd(dxh, x, stats[0], stats[1], relu_mask=mask_input, relu_scale=in_scale)
+        return dx, None, None, None, None, None, None, None, None
+
+
+class DwConv3x3Fn(Function):
+    """[InstanceNorm ->] depthwise 3x3 + bias on NHWC (DepthSepConv2D.depth_conv, encoder.py:56-64,74)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, use_norm, mask_input, in_scale):
+        stats = K.instnorm_stats(x) if use_norm else None
+        y = K.dwconv3x3(x, wt(weight, x.dtype), bias.omr_phys, in_stats=stats)
+        ctx.cfg = (mask_input, in_scale)
+        ctx.weight, ctx.bias, ctx.stats = weight, bias, stats
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        mask_input, in_scale = ctx.cfg
+        (x,) = ctx.saved_tensors
+        weight, bias, stats = ctx.weight, ctx.bias, ctx.stats
+        g = gy.contiguous()
+        K.dwconv3x3_wgrad(x, g, weight.omr_grad, bias.omr_grad, in_stats=stats)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w = wt(weight, x.dtype)
+            if stats is None:
+                dx = K.dwconv3x3(g, w, None, flip=True, out_mask=x if mask_input else None, mask_scale=in_scale)
+            else:
+                dxh = K.dwconv3x3(g, w, None, flip=True)
+                dx = K.instnorm_bwd(dxh, x, stats[0], stats[1], relu_mask=mask_input, relu_scale=in_scale)
+        return dx, None, None, None, None, None
+
+
+class LinearFn(Function):
+    """y = x W^T + b [-> ReLU] over the last dim (nn.Linear, 1x1 point_conv on NHWC, Conv1d(k=1) head).
+    ``rows=(a, b)`` uses rows [a, b) of the weight/bias (packed MHA in_proj: q rows / k|v rows).
+    ``out_ld`` > N pads the output row stride (head: vocabulary rounded up to 8 for aligned rows)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, mask_own, out_ld, rows):
+        w = wt(weight, x.dtype)
+        w = w.view(w.shape[0], -1)           # [N_all, K]
+        b = None if bias is None else bias.omr_phys
+        if rows is not None:
+            w = w[rows[0]:rows[1]]
+            b = None if b is None else b[rows[0]:rows[1]]
+        N, Kd = w.shape
+        x2 = x.reshape(-1, Kd)
+        M = x2.shape[0]
+        if out_ld and out_ld != N:
+            buf = torch.empty((M, out_ld), dtype=x.dtype, device=x.device)
+            y2 = K.gemm(x2, w, bias=b, relu=relu, out=buf[:, :N])
+        else:
+            y2 = K.gemm(x2, w, bias=b, relu=relu)
+        ctx.cfg = (relu, mask_own, tuple(x.shape), rows)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.save_for_backward(x2, y2 if (relu and mask_own) else None)
+        return y2.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        relu, mask_own, xshape, rows = ctx.cfg
+        x2, y2 = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        w = wt(weight, x2.dtype)
+        w = w.view(w.shape[0], -1)
+        gw = weight.omr_grad.view(w.shape)
+        gb = None if bias is None else bias.omr_grad
+        if rows is not None:
+            w, gw = w[rows[0]:rows[1]], gw[rows[0]:rows[1]]
+            gb = None if gb is None else gb[rows[0]:rows[1]]
+        N, Kd = w.shape
+        g2 = gy.reshape(-1, N)
+        if g2.stride(1) != 1 or g2.stride(0) % 8:
+            g2 = g2.contiguous()
+        if relu and mask_own:
+            g2 = K.relu_bwd(g2.contiguous(), y2)
+        M = g2.shape[0]
+        if gb is not None:
+            K.colsum_into(g2, gb)
+        K.gemm(g2, x2, trans_a=True, trans_b=True, out=gw, accumulate=True, split_k=split_k_for(M))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.gemm(g2, w, trans_b=True).view(xshape)
+        return dx, None, None, None, None, None, None
+
+
+def linear(x, weight, bias, relu=False, mask_own=True, out_ld=0, rows=None):
+    return LinearFn.apply(x, weight, bias, relu, mask_own, out_ld, rows)
+
+
+class AddFn(Function):
+    """Residual add (encoder.py:289)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return K.add(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class AddPE2DFn(Function):
+    """x + pe[:, :, :h, :w] on NHWC (PositionalEncoding2D.forward, model.py:45-47)."""
+
+    @staticmethod
+    def forward(ctx, x, pe_hwc):
+        return K.add_pe2d(x, pe_hwc)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class DropoutFn(Function):
+    """nn.Dropout / nn.Dropout2d with a counter-based mask that is regenerated (not stored) in backward.
+    bwd_identity: the consumer applies (x > 0) * 1/(1-p) itself (see module docstring)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, channel_mode, bwd_identity):
+        ctx.cfg = (p, seed, channel_mode, bwd_identity)
+        return K.dropout(x.contiguous(), p, seed, channel_mode)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed, channel_mode, bwd_identity = ctx.cfg
+        if bwd_identity:
+            return g, None, None, None, None
+        return K.dropout(g.contiguous(), p, seed, channel_mode), None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ decoder
+
+class EmbedPEFn(Function):
+    """embedding(tgt) + pe[:, :T] (decoder.py:124)."""
+
+    @staticmethod
+    def forward(ctx, tokens, table, pe, pad_idx, dtype):
+        ctx.table, ctx.pad_idx = table, pad_idx
+        ctx.save_for_backward(tokens)
+        return K.embed_pe(tokens, wt(table, dtype), pe)
+
+    @staticmethod
+    def backward(ctx, g):
+        (tokens,) = ctx.saved_tensors
+        K.embed_bwd(tokens, g.contiguous(), ctx.table.omr_grad, ctx.pad_idx)
+        return None, None, None, None, None
+
+
+class AddLayerNormFn(Function):
+    """LayerNorm(x + res) (post-norm residual, torch nn/modules/transformer.py:1146-1154)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta):
+        out, mean, rstd = K.add_layernorm_fwd(x.contiguous(), res.contiguous(), gamma.omr_phys, beta.omr_phys)
+        ctx.gamma, ctx.beta = gamma, beta
+        ctx.save_for_backward(x, res, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, res, mean, rstd = ctx.saved_tensors
+        ds = K.add_layernorm_bwd(gy.contiguous(), x.contiguous(), res.contiguous(), ctx.gamma.omr_phys, mean, rstd, ctx.gamma.omr_grad, ctx.beta.omr_grad)
+        return ds, ds, None, None
+
+
+class AttentionFn(Function):
+    """Fused attention core over packed projections.
+    self mode : qkv [B,T,3d] -> o [B,T,d]           (backward returns d(qkv) packed)
+    cross mode: q [B,T,d], kv [B,S,2d] -> o [B,T,d] (backward returns dq and d(kv) packed)"""
+
+    @staticmethod
+    def forward(ctx, q_or_qkv, kv, nhead, causal, window, key_bias, blk_lq, blk_lkv, dropout_p, seed):
+        if kv is None:
+            d = q_or_qkv.shape[-1] // 3
+            q, k, v = q_or_qkv[..., :d], q_or_qkv[..., d:2 * d], q_or_qkv[..., 2 * d:]
+        else:
+            d = q_or_qkv.shape[-1]
+            q, k, v = q_or_qkv, kv[..., :d], kv[..., d:]
+        o, lse = K.attn_fwd(q, k, v, nhead, causal=causal, window=window, key_bias=key_bias, blk_lq=blk_lq, blk_lkv=blk_lkv,
+                            dropout_p=dropout_p, seed=seed)
+        ctx.cfg = (nhead, causal, window, dropout_p, seed, kv is None, d)
+        ctx.save_for_backward(q_or_qkv, kv, o, lse, key_bias, blk_lq, blk_lkv)
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        nhead, causal, window, dropout_p, seed, packed, d = ctx.cfg
+        q_or_qkv, kv, o, lse, key_bias, blk_lq, blk_lkv = ctx.saved_tensors
+        go = go.contiguous()
+        if packed:
+            dqkv = torch.empty_like(q_or_qkv)
+            q, k, v = q_or_qkv[..., :d], q_or_qkv[..., d:2 * d], q_or_qkv[..., 2 * d:]
+            dq, dk, dv = dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:]
+            dkv = None
+        else:
+            dqkv = torch.empty_like(q_or_qkv)
+            dkv = torch.empty_like(kv)
+            q, k, v = q_or_qkv, kv[..., :d], kv[..., d:]
+            dq, dk, dv = dqkv, dkv[..., :d], dkv[..., d:]
+        K.attn_bwd(q, k, v, o, go, lse, dq, dk, dv, nhead, causal=causal, window=window, key_bias=key_bias, blk_lq=blk_lq, blk_lkv=blk_lkv,
+                   dropout_p=dropout_p, seed=seed)
+        return dqkv, dkv, None, None, None, None, None, None, None, None
+
+
+class CrossEntropyFn(Function):
+    """CrossEntropyLoss(ignore_index) on row-major logits [M, V] (model.py:109,166)."""
+
+    @staticmethod
+    def forward(ctx, logits2d, target, V, pad_idx):
+        loss, lse, acc2 = K.ce_fwd(logits2d, target, V, pad_idx)
+        ctx.cfg = (V, pad_idx)
+        ctx.save_for_backward(logits2d, target, lse, acc2)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        V, pad_idx = ctx.cfg
+        logits2d, target, lse, acc2 = ctx.saved_tensors
+        dl = K.ce_bwd(logits2d, target, lse, acc2, V, pad_idx, grad_out=g)
+        return dl, None, None, None
+
+
+def cross_entropy(logits_bvt: Tensor, target_bt: Tensor, pad_idx: int) -> Tensor:
+    """Loss on logits in the reference's [B, V, T] layout.  The decoder produces them as a stride
+    permutation of row-major [B*T, V], which is what the kernel consumes (no copy)."""
+    B, V, T = logits_bvt.shape
+    rows = logits_bvt.permute(0, 2, 1)
+    if rows.stride(2) != 1 or rows.stride(1) % 8 or rows.stride(0) != T * rows.stride(1):
+        rows = rows.contiguous()
+    l2 = rows.reshape(B * T, V)   # a view: rows of one batch follow each other at the same pitch
+    return CrossEntropyFn.apply(l2, target_bt.reshape(-1).contiguous(), V, pad_idx)

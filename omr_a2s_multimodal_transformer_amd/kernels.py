@@ -325,12 +325,15 @@ def ce_fwd(logits2d: Tensor, target: Tensor, V: int, pad_idx: int):
     return loss, lse, acc2
 
 
-def ce_bwd(logits2d: Tensor, target: Tensor, lse: Tensor, acc2: Tensor, V: int, pad_idx: int, grad_scale: float = 1.0) -> Tensor:
-    require_cuda(logits2d, target)
+def ce_bwd(logits2d: Tensor, target: Tensor, lse: Tensor, acc2: Tensor, V: int, pad_idx: int, grad_scale: float = 1.0,
+           grad_out: Optional[Tensor] = None) -> Tensor:
+    require_cuda(logits2d, target, grad_out)
+    if grad_out is not None:
+        assert grad_out.dtype == torch.float32 and grad_out.numel() == 1
     M, cols, ldv = _rows2d(logits2d)
     dl = torch.empty((M, ldv), dtype=logits2d.dtype, device=logits2d.device)
     lib().call("omr_ce_bwd", dtype_code(logits2d.dtype), ptr(logits2d), ptr(target), ptr(lse), ptr(acc2), ptr(dl), M, V, ldv, pad_idx, float(grad_scale),
-               cur_stream())
+               ptr(grad_out), cur_stream())
     return dl[:, :cols]
 
 

@@ -1,0 +1,119 @@
+"""Flat parameter storage sized for one HBM-resident model replica + fused Adam.
+
+All parameters of a model live in ONE fp32 buffer (master weights) with parallel flat buffers for
+gradients, Adam moments and (bf16 mode) the bf16 compute copy.  nn.Parameters are views into the master
+buffer that keep the reference's logical shapes (state-dict contract) while the memory
+is laid out for the kernels: conv weights [Cout,Cin,kh,kw] are stored [Cout,kh,kw,Cin] (the logical
+tensor is the channels_last-strided permutation), so MFMA B-fragments are 16-byte k-contiguous loads.
+One flat buffer means: Adam is a single kernel launch (omr_adam), zero_grad is one memset and the
+data-parallel gradient all-reduce runs over a few large contiguous buckets (ddp.py).
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+
+ALIGN = 64  # elements; keeps every view 256-byte aligned in fp32 and 128-byte aligned in bf16
+
+
+def _phys_perm(ndim: int) -> Optional[Tuple[int, ...]]:
+    """logical dims -> physical order: channel dim 1 moves last for conv weights (ndim >= 3)."""
+    if ndim < 3:
+        return None
+    return (0,) + tuple(range(2, ndim)) + (1,)
+
+
+def _inverse(perm: Tuple[int, ...]) -> Tuple[int, ...]:
+    inv = [0] * len(perm)
+    for i, p in enumerate(perm):
+        inv[p] = i
+    return tuple(inv)
+
+
+class FlatParams:
+    def __init__(self, named_params: List[Tuple[str, nn.Parameter]], device: torch.device, compute_dtype: torch.dtype):
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        self.device = device
+        self.compute_dtype = compute_dtype
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        for n, p in named_params:
+            self.offsets[n] = (off, p.numel())
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        self.master = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self.lowp = torch.zeros(off, dtype=torch.bfloat16, device=device) if compute_dtype == torch.bfloat16 else None
+        self.exp_avg: Optional[torch.Tensor] = None
+        self.exp_avg_sq: Optional[torch.Tensor] = None
+        with torch.no_grad():
+            for n, p in named_params:
+                o, cnt = self.offsets[n]
+                perm = _phys_perm(p.dim())
+                phys_shape = tuple(p.shape) if perm is None else tuple(p.shape[i] for i in perm)
+
+                def views(buf):
+                    phys = buf[o:o + cnt].view(phys_shape)
+                    logical = phys if perm is None else phys.permute(_inverse(perm))
+                    return phys, logical
+
+                phys, logical = views(self.master)
+                logical.copy_(p.detach().to(device=device, dtype=torch.float32))
+                p.data = logical
+                p.omr_phys = phys
+                gphys, glogical = views(self.grad)
+                p.omr_grad = gphys
+                p.grad = glogical
+                p.omr_lowp = views(self.lowp)[0] if self.lowp is not None else None
+        self.sync_lowp()
+
+    def sync_lowp(self) -> None:
+        """Refresh the bf16 compute copy from the fp32 masters (after load_state_dict / manual edits)."""
+        if self.lowp is not None:
+            K.cast(self.master, torch.bfloat16, out=self.lowp)
+
+    def zero_grad(self) -> None:
+        self.grad.zero_()
+
+    def slice_of(self, names: Iterable[str]) -> Tuple[int, int]:
+        """[begin, end) element range of the flat buffers that covers the given parameters."""
+        offs = [self.offsets[n] for n in names]
+        b = min(o for o, _ in offs)
+        e = max((o + c + ALIGN - 1) // ALIGN * ALIGN for o, c in offs)
+        return b, e
+
+
+class FusedAdam:
+    """torch.optim.Adam(lr=1e-4, amsgrad=False) semantics (model.py:134-139,475-483) as one kernel over the
+    flat buffers.  Interface subset of torch.optim.Optimizer: step / zero_grad / param_groups / state_dict."""
+
+    def __init__(self, flat: FlatParams, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.flat = flat
+        self.param_groups = [dict(params=flat.params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)]
+        self.step_count = 0
+        if flat.exp_avg is None:
+            flat.exp_avg = torch.zeros_like(flat.master)
+            flat.exp_avg_sq = torch.zeros_like(flat.master)
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        self.flat.zero_grad()
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        g = self.param_groups[0]
+        self.step_count += 1
+        f = self.flat
+        K.adam_step(f.master, f.grad, f.exp_avg, f.exp_avg_sq, self.step_count, g["lr"], g["betas"], g["eps"], grad_scale, p_lowp=f.lowp)
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.flat.exp_avg, exp_avg_sq=self.flat.exp_avg_sq, param_groups=[
+            {k: v for k, v in self.param_groups[0].items() if k != "params"}])
+
+    def load_state_dict(self, sd) -> None:
+        self.step_count = int(sd["step"])
+        self.flat.exp_avg.copy_(sd["exp_avg"])
+        self.flat.exp_avg_sq.copy_(sd["exp_avg_sq"])

@@ -1,0 +1,71 @@
+"""Process-wide runtime state of the HIP path: dropout seed stream and flat-parameter management mixin."""
+from __future__ import annotations
+
+import random as _pyrandom
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .params import FlatParams, FusedAdam
+
+# Dropout masks are counter-based (csrc/omr_common.h hash_u32): every dropout site draws a fresh 63-bit
+# seed from this stream.  It is separate from Python's global `random`, whose draws the modules consume
+# exactly as the reference does (encoder.py:102,160,219; model.py:568-575) so rank-consistent choices
+# (dropout position / modality) stay in lock-step across data-parallel ranks.
+_seed_stream = _pyrandom.Random(0x5EED)
+
+
+def seed_dropout(seed: int, rank: int = 0) -> None:
+    _seed_stream.seed(seed * 1000003 + rank)
+
+
+def next_seed() -> int:
+    return _seed_stream.getrandbits(63)
+
+
+class FlatModuleMixin:
+    """Adds flat-buffer parameter storage (params.py) to a top-level nn.Module."""
+
+    _flat: Optional[FlatParams] = None
+
+    def compute_dtype(self) -> torch.dtype:
+        return self._flat.compute_dtype if self._flat is not None else torch.float32
+
+    def flatten_parameters(self, compute_dtype: Optional[torch.dtype] = None, device=None) -> FlatParams:
+        """(Re)build the flat master/grad/compute buffers on `device` (default cuda:current) and re-point
+        every nn.Parameter at its view.  Call after .load_state_dict on CPU, or to switch compute dtype."""
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if compute_dtype is None:
+            compute_dtype = self._flat.compute_dtype if self._flat is not None else getattr(self, "_default_compute_dtype", torch.float32)
+        named = [(n, p) for n, p in self.named_parameters()]
+        self._flat = FlatParams(named, torch.device(device), compute_dtype)
+        for mod in self.modules():
+            for name, buf in list(mod._buffers.items()):
+                if buf is not None and buf.device != self._flat.device:
+                    mod._buffers[name] = buf.to(self._flat.device)
+        return self._flat
+
+    def ensure_flat(self) -> FlatParams:
+        if self._flat is None:
+            self.flatten_parameters()
+        return self._flat
+
+    def sync_compute_weights(self) -> None:
+        if self._flat is not None:
+            self._flat.sync_lowp()
+
+    def zero_grad(self, set_to_none: bool = False) -> None:  # type: ignore[override]
+        if self._flat is not None:
+            self._flat.zero_grad()
+        else:
+            nn.Module.zero_grad(self, set_to_none)
+
+    def make_optimizer(self, lr: float = 1e-4) -> FusedAdam:
+        return FusedAdam(self.ensure_flat(), lr=lr)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):  # type: ignore[override]
+        out = nn.Module.load_state_dict(self, state_dict, strict=strict)
+        self.sync_compute_weights()
+        return out
