@@ -1,0 +1,99 @@
+"""Data-parallel gradient averaging over RCCL/xGMI (backend "nccl" on ROCm) or gloo (CPU tests).
+
+The reference has no explicit DDP code: multi-GPU training happens only through Lightning's default
+DistributedDataParallel.  Here one process drives one GPU and gradients live in ONE flat
+fp32 buffer (params.py), so the exchange step is an all-reduce(sum) of a few large contiguous buckets followed
+by a 1/world scale that is folded into the fused Adam kernel (grad_scale) -- no per-tensor work at all.
+
+Overlap with backward: autograd "bucket boundary" nodes (GradBoundary) are placed in the forward graph where
+all parameters of a bucket have finished accumulating (decoder after the memory gradient is complete, encoder
+stages after their block).  When backward reaches a boundary, the bucket's all-reduce is enqueued on a side
+HIP stream behind an event recorded on the compute stream, so RCCL traffic over xGMI runs under the remaining
+backward kernels.  finish() makes the compute stream wait for all outstanding buckets before Adam.
+
+Unused parameters (MultimodalTransformer drops a modality in ~20 % of the steps, model.py:510-519): their slice of
+the flat buffer simply stays zero and is reduced like any other -- every rank reduces the same buckets every
+step, so there is nothing to negotiate and nothing can hang.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+from torch.autograd import Function
+
+
+class GradReducer:
+    def __init__(self, flat, process_group=None, buckets: Optional[Sequence[Tuple[int, int]]] = None, async_stream: bool = True):
+        self.flat = flat
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.buckets: List[Tuple[int, int]] = list(buckets) if buckets else [(0, flat.total)]
+        self.done = [False] * len(self.buckets)
+        self.handles: List = []
+        self.use_stream = async_stream and flat.grad.is_cuda
+        self.stream = torch.cuda.Stream(device=flat.device) if self.use_stream else None
+
+    @property
+    def grad_scale(self) -> float:
+        """Factor that turns the all-reduced SUM into Lightning-DDP's mean (applied inside omr_adam)."""
+        return 1.0 / self.world
+
+    def reduce_bucket(self, i: int) -> None:
+        """Enqueue bucket i's all-reduce (idempotent per step)."""
+        if self.world == 1 or self.done[i]:
+            return
+        self.done[i] = True
+        b, e = self.buckets[i]
+        view = self.flat.grad[b:e]
+        if self.use_stream:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self) -> None:
+        """Reduce whatever has not been reduced yet and order the optimizer after all buckets."""
+        for i in range(len(self.buckets)):
+            self.reduce_bucket(i)
+        if self.use_stream and self.world > 1:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+        for h in self.handles:
+            h.wait()
+        self.handles.clear()
+        self.done = [False] * len(self.buckets)
+
+
+class GradBoundary(Function):
+    """Identity in forward; in backward, signals that every gradient produced AFTER this point of the forward
+    (i.e. earlier in backward) is final, and launches the given buckets' all-reduce."""
+
+    @staticmethod
+    def forward(ctx, x, reducer, bucket_ids):
+        ctx.reducer, ctx.bucket_ids = reducer, bucket_ids
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.reducer is not None:
+            for i in ctx.bucket_ids:
+                ctx.reducer.reduce_bucket(i)
+        return g, None, None
+
+
+def shard_indices(n_samples: int, rank: int, world: int, epoch: int = 0, shuffle: bool = True, seed: int = 0) -> List[int]:
+    """DistributedSampler semantics (what Lightning injects): shared-seed shuffle per epoch,
+    pad by wrap-around to a multiple of world, rank r takes indices r::world."""
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        idx = torch.randperm(n_samples, generator=g).tolist()
+    else:
+        idx = list(range(n_samples))
+    total = (n_samples + world - 1) // world * world
+    idx += idx[: total - n_samples]
+    return idx[rank:total:world]

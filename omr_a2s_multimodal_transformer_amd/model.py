@@ -101,6 +101,26 @@ class _Base(FlatModuleMixin, LightningModule):
                        padding_idx=self.padding_idx, ff_dim=c.ff_dim, dropout_p=c.dropout, nhead=c.nhead,
                        num_transformer_layers=c.num_layers, attn_window=self.attn_window)
 
+    # ---- data parallel (ddp.py): bucket boundaries are autograd nodes placed where a bucket's gradients are final
+    _reducer = None
+
+    def attach_reducer(self, process_group=None):
+        """One bucket per top-level sub-module (encoder(s) | decoder+mixer), reduced as backward leaves it."""
+        from .ddp import GradReducer
+        flat = self.ensure_flat()
+        enc_names = [n for n in flat.names if n.startswith(("encoder.", "image_encoder.", "audio_encoder."))]
+        dec_names = [n for n in flat.names if n not in set(enc_names)]
+        buckets = [flat.slice_of(enc_names), flat.slice_of(dec_names)]
+        self._reducer = GradReducer(flat, process_group, buckets)
+        return self._reducer
+
+    def _boundary(self, mem: torch.Tensor) -> torch.Tensor:
+        """Memory hand-off encoder -> decoder: when backward gets here every decoder-side gradient is final."""
+        if self._reducer is None or not torch.is_grad_enabled():
+            return mem
+        from .ddp import GradBoundary
+        return GradBoundary.apply(mem, self._reducer, (1,))
+
     def configure_optimizers(self):
         """torch.optim.Adam(lr=1e-4, amsgrad=False) over all parameters (model.py:134-139,475-483) as ONE fused kernel."""
         return self.make_optimizer(lr=1e-4)
@@ -178,7 +198,7 @@ class Transformer(_Base):
         flat = self.ensure_flat()
         x = x.to(flat.device)
         f = self.encoder.forward_nhwc(x, flat.compute_dtype).permute(0, 3, 1, 2)
-        return _flatten_memory(self.pos_2d(f))
+        return self._boundary(_flatten_memory(self.pos_2d(f)))
 
     def forward(self, x: torch.Tensor, xl: torch.Tensor, y_in: torch.Tensor) -> torch.Tensor:
         mem = self.encode(x)
