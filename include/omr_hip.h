@@ -76,8 +76,8 @@ int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const float* bias, 
                     const void* out_mask, float mask_scale, int B, int H, int W, int CIN, int COUT, int stride_h, int stride_w, int dil_h,
                     int dil_w, int Ho, int Wo, int relu, void* stream);
 int omr_conv3x3_weight_flip(int dtype, const void* w, void* wd, int COUT, int CIN, void* stream);
-/* dw[COUT][3][3][CIN] (fp32) += dy^T * im2col(x) */
-int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, const float* in_mean, const float* in_rstd, int B, int H, int W,
+/* dw[COUT][3][3][CIN] (fp32) += dy^T * im2col(x);  db[COUT] (nullable, fp32) += column sums of dy (bias gradient) */
+int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, const float* in_mean, const float* in_rstd, int B, int H, int W,
                       int CIN, int COUT, int stride_h, int stride_w, int Ho, int Wo, void* stream);
 /* depthwise 3x3, stride 1, pad 1 (DepthSepConv2D.depth_conv, encoder.py:56-64); flip=1 mirrors the taps (data gradient) */
 int omr_dwconv3x3(int dtype, const void* x, const void* w, const float* bias, void* y, const float* in_mean, const float* in_rstd,

@@ -193,7 +193,7 @@ __global__ void weight_flip_kernel(const T* __restrict__ w, T* __restrict__ wd, 
 // the block walks pixel tiles (grid-stride), stages dY[pix][64 n] and the X halo [pix][64 c] in LDS
 // and reads k-strided operand fragments element-wise (dtype generic; bf16 tr-reads are a later step).
 struct WgradArgs {
-    const void* x; const void* dy; float* dw;
+    const void* x; const void* dy; float* dw; float* db;
     const float* mean; const float* rstd;
     int B, Hr, Wr, CIN, Ho, Wo, COUT, sh, sw, tiles_w, tiles_h;
 };
@@ -221,6 +221,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const int ntiles = a.B * a.tiles_h * a.tiles_w;
+    const bool do_bias = a.db != nullptr && (blockIdx.y % ncb) == 0;   // one cin-block column of the grid owns the bias sums
+    float bsum = 0.f;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / (a.tiles_h * a.tiles_w);
         const int rem = tile % (a.tiles_h * a.tiles_w);
@@ -255,6 +257,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
             for (int e = 0; e < VEC; ++e) Xs[(long)pix * CP + kc + e] = v[e];
         }
         __syncthreads();
+        if (do_bias) {   // bias gradient: column sums of the staged dY tile (thread = channel x pixel phase)
+            constexpr int NPH = 256 / CBN;
+            const int ch = tid % CBN;
+            for (int pix = tid / CBN; pix < TH * TW; pix += NPH) bsum += to_f32(Ys[(long)pix * NP + ch]);
+        }
         const int nl = wn * 32 + (lane & 31), cl = wc * 32 + (lane & 31);
         for (int k0 = wk * KStep<T>::value; k0 < TH * TW; k0 += WK * KStep<T>::value) {
             const int pbase = k0 + (lane >> 5) * VEC;     // VEC consecutive pixels of one tile row
@@ -271,6 +278,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
                 mma32(acc[tap], af, bf);
             }
         }
+    }
+    if (do_bias) {
+        const int n = n0 + tid % CBN;
+        if (n < a.COUT) atomicAdd(&a.db[n], bsum);
     }
     // accumulate: dw[n][tap][c] (fp32 atomics; the grad buffer is zeroed once per step)
     const int c = c0 + wc * 32 + (lane & 31);
@@ -348,18 +359,19 @@ __global__ void conv1_direct_kernel(const T* __restrict__ x, const T* __restrict
 }
 // dW[n][tap] += sum_p dY[p][n] x[p + tap];  thread = (channel n = tid % COUT, pixel phase)
 template <typename T, int COUT>
-__global__ void conv1_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, int B, int H, int Wd) {
-    __shared__ float red[COUT * 9];
-    for (int i = threadIdx.x; i < COUT * 9; i += blockDim.x) red[i] = 0.f;
+__global__ void conv1_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db, int B, int H, int Wd) {
+    __shared__ float red[COUT * 10];
+    for (int i = threadIdx.x; i < COUT * 10; i += blockDim.x) red[i] = 0.f;
     __syncthreads();
     const int n = threadIdx.x % COUT, phase = threadIdx.x / COUT, nphase = blockDim.x / COUT;
     const long total = (long)B * H * Wd;
-    float accw[9];
+    float accw[9], accb = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) accw[t] = 0.f;
     for (long p = (long)blockIdx.x * nphase + phase; p < total; p += (long)gridDim.x * nphase) {
         const int j = (int)(p % Wd); const long q = p / Wd; const int i = (int)(q % H); const long b = q / H;
         const float g = to_f32(dy[p * COUT + n]);
+        accb += g;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int ii = i + t / 3 - 1, jj = j + t % 3 - 1;
@@ -369,8 +381,10 @@ __global__ void conv1_wgrad_kernel(const T* __restrict__ x, const T* __restrict_
     }
 #pragma unroll
     for (int t = 0; t < 9; ++t) atomicAdd(&red[n * 9 + t], accw[t]);
+    atomicAdd(&red[COUT * 9 + n], accb);
     __syncthreads();
     for (int i = threadIdx.x; i < COUT * 9; i += blockDim.x) atomicAdd(&dw[i], red[i]);
+    if (db) for (int i = threadIdx.x; i < COUT; i += blockDim.x) atomicAdd(&db[i], red[COUT * 9 + i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -417,42 +431,52 @@ __global__ void dwconv3x3_kernel(const T* __restrict__ x, const T* __restrict__ 
     }
 }
 
-// dW[c][tap] += sum_p dY[p][c] xin[p+tap][c];  db[c] += sum_p dY[p][c].  Block = 256 threads covers
-// channels (tid % C-group) x pixel phases; LDS reduction then one fp32 atomic per (c, tap) per block.
+// dW[c][tap] += sum_p dY[p][c] xin[p+tap][c];  db[c] += sum_p dY[p][c].  Thread = (8/4-channel group, pixel phase) with
+// 16-byte loads; per-thread register partials -> LDS fp32 -> one global fp32 atomic per (c, tap) per block.
 template <typename T>
-__global__ void dwconv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db,
-                                       const float* __restrict__ mean, const float* __restrict__ rstd, int B, int H, int Wd, int C,
-                                       int pix_per_block) {
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw,
+                                                              float* __restrict__ db, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, int B, int H, int Wd, int C, int pix_per_block) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N;
     extern __shared__ __attribute__((aligned(16))) float red[];  // [C][10]
     for (int i = threadIdx.x; i < C * 10; i += blockDim.x) red[i] = 0.f;
     __syncthreads();
-    const bool wide = (int)blockDim.x >= C;
-    const int cstride = wide ? C : (int)blockDim.x;
-    const int nphase = wide ? (int)blockDim.x / C : 1;
-    const int phase = wide ? (int)threadIdx.x / C : 0;
+    const int ncg = C / VEC;
+    const int cg = threadIdx.x % ncg, phase = threadIdx.x / ncg, nphase = blockDim.x / ncg;
     const long total = (long)B * H * Wd;
     const long p0 = (long)blockIdx.x * pix_per_block;
     const long p1 = p0 + pix_per_block < total ? p0 + pix_per_block : total;
+    float acc[10][VEC];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
     if (phase < nphase) {
-        for (int c = threadIdx.x % cstride; c < C; c += cstride) {
-            float a[10];
+        for (long p = p0 + phase; p < p1; p += nphase) {
+            const int j = (int)(p % Wd); const long q = p / Wd; const int ii = (int)(q % H); const long b = q / H;
+            const F gv = *reinterpret_cast<const F*>(dy + p * C + cg * VEC);
+            float g[VEC], mu[VEC], rs[VEC];
 #pragma unroll
-            for (int t = 0; t < 10; ++t) a[t] = 0.f;
-            for (long p = p0 + phase; p < p1; p += nphase) {
-                const int j = (int)(p % Wd); const long q = p / Wd; const int ii = (int)(q % H); const long b = q / H;
-                const float g = to_f32(dy[p * C + c]);
-                const float mu = mean ? mean[b * C + c] : 0.f, rs = rstd ? rstd[b * C + c] : 1.f;
-                a[9] += g;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int yy = ii + t / 3 - 1, xx = j + t % 3 - 1;
-                    if (yy < 0 || yy >= H || xx < 0 || xx >= Wd) continue;
-                    a[t] += g * ((to_f32(x[((b * H + yy) * Wd + xx) * C + c]) - mu) * rs);
-                }
+            for (int e = 0; e < VEC; ++e) {
+                g[e] = to_f32(gv[e]);
+                acc[9][e] += g[e];
+                mu[e] = mean ? mean[b * C + cg * VEC + e] : 0.f;
+                rs[e] = rstd ? rstd[b * C + cg * VEC + e] : 1.f;
             }
 #pragma unroll
-            for (int t = 0; t < 10; ++t) atomicAdd(&red[c * 10 + t], a[t]);
+            for (int t = 0; t < 9; ++t) {
+                const int yy = ii + t / 3 - 1, xx = j + t % 3 - 1;
+                if (yy < 0 || yy >= H || xx < 0 || xx >= Wd) continue;
+                const F xv = *reinterpret_cast<const F*>(x + ((b * H + yy) * Wd + xx) * C + cg * VEC);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[t][e] += g[e] * ((to_f32(xv[e]) - mu[e]) * rs[e]);
+            }
         }
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) atomicAdd(&red[(cg * VEC + e) * 10 + t], acc[t][e]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < C * 10; i += blockDim.x) {
@@ -504,7 +528,7 @@ extern "C" int omr_conv3x3_weight_flip(int dtype, const void* w, void* wd, int C
     return OMR_OK;
 }
 
-extern "C" int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, const float* in_mean, const float* in_rstd, int B, int H,
+extern "C" int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, const float* in_mean, const float* in_rstd, int B, int H,
                                  int W, int CIN, int COUT, int stride_h, int stride_w, int Ho, int Wo, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0 || CIN <= 0 || COUT <= 0 || !x || !dy || !dw) return OMR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -513,8 +537,8 @@ extern "C" int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float
         long total = (long)B * H * W;
         int grid = (int)((total + 4095) / 4096); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
         DISPATCH_T(dtype, {
-            if (COUT == 16) hipLaunchKernelGGL((conv1_wgrad_kernel<T, 16>), grid, 256, 0, s, (const T*)x, (const T*)dy, dw, B, H, W);
-            else if (COUT == 32) hipLaunchKernelGGL((conv1_wgrad_kernel<T, 32>), grid, 256, 0, s, (const T*)x, (const T*)dy, dw, B, H, W);
+            if (COUT == 16) hipLaunchKernelGGL((conv1_wgrad_kernel<T, 16>), grid, 256, 0, s, (const T*)x, (const T*)dy, dw, db, B, H, W);
+            else if (COUT == 32) hipLaunchKernelGGL((conv1_wgrad_kernel<T, 32>), grid, 256, 0, s, (const T*)x, (const T*)dy, dw, db, B, H, W);
             else return OMR_ERR_UNSUPPORTED;
         });
         OMR_CHECK_LAUNCH();
@@ -523,7 +547,7 @@ extern "C" int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float
     const int vec = dtype == OMR_BF16 ? 8 : 4;
     if (CIN % vec || COUT % vec) return OMR_ERR_UNSUPPORTED;
     WgradArgs a;
-    a.x = x; a.dy = dy; a.dw = dw; a.mean = in_mean; a.rstd = in_rstd; a.B = B; a.Hr = H; a.Wr = W; a.CIN = CIN; a.Ho = Ho; a.Wo = Wo;
+    a.x = x; a.dy = dy; a.dw = dw; a.db = db; a.mean = in_mean; a.rstd = in_rstd; a.B = B; a.Hr = H; a.Wr = W; a.CIN = CIN; a.Ho = Ho; a.Wo = Wo;
     a.COUT = COUT; a.sh = stride_h; a.sw = stride_w; a.tiles_w = a.tiles_h = 0;
     const bool strided = stride_h > 1 || stride_w > 1;
     if (dtype == OMR_BF16) return strided ? launch_wgrad<bf16, 4>(a, s) : launch_wgrad<bf16, 8>(a, s);
@@ -546,8 +570,10 @@ extern "C" int omr_dwconv3x3(int dtype, const void* x, const void* w, const floa
 extern "C" int omr_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, const float* in_mean, const float* in_rstd,
                                    int B, int H, int W, int C, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return OMR_ERR_ARG;
+    const int vec = dtype == OMR_BF16 ? 8 : 4;
+    if (C % vec || 256 % (C / vec)) return OMR_ERR_UNSUPPORTED;
     long total = (long)B * H * W;
-    int ppb = 512;
+    int ppb = 128;
     int grid = (int)((total + ppb - 1) / ppb);
     size_t shm = (size_t)C * 10 * sizeof(float);
     DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<T>), grid, 256, shm, (hipStream_t)stream, (const T*)x, (const T*)dy, dw, db,

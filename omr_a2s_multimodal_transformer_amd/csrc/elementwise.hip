@@ -55,10 +55,25 @@ template <typename T> __global__ void relu_bwd_kernel(const T* __restrict__ dy, 
 // channels, encoder.py:99); otherwise the flat element index.
 template <typename T> __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ o, long n, uint32_t thresh, float scale,
                                                      uint64_t seed, int channel_mode, long per_sample, int C) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        uint64_t idx = channel_mode ? (uint64_t)((i / per_sample) * C + (i % C)) : (uint64_t)i;
-        o[i] = drop_keep(seed, idx, thresh) ? from_f32<T>(to_f32(x[i]) * scale) : from_f32<T>(0.f);
+    typedef typename Vec<T>::type V;
+    constexpr int N = Vec<T>::N;
+    const long nv = n / N;     // callers pass tensors whose channel count is a multiple of N (or tiny tails handled below)
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+        const V v = reinterpret_cast<const V*>(x)[i];
+        V r;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const long k = i * N + e;
+            const uint64_t idx = channel_mode ? (uint64_t)((k / per_sample) * C + (k % C)) : (uint64_t)k;
+            r[e] = drop_keep(seed, idx, thresh) ? from_f32<T>(to_f32(v[e]) * scale) : from_f32<T>(0.f);
+        }
+        reinterpret_cast<V*>(o)[i] = r;
     }
+    if (blockIdx.x == 0)
+        for (long k = nv * N + threadIdx.x; k < n; k += blockDim.x) {
+            const uint64_t idx = channel_mode ? (uint64_t)((k / per_sample) * C + (k % C)) : (uint64_t)k;
+            o[k] = drop_keep(seed, idx, thresh) ? from_f32<T>(to_f32(x[k]) * scale) : from_f32<T>(0.f);
+        }
 }
 
 // ---------------------------------------------------------------- embedding gather + 1-D positional encoding
@@ -97,15 +112,19 @@ template <typename T> __global__ void add_pe2d_kernel(const T* __restrict__ x, c
 }
 
 // ---------------------------------------------------------------- column sums:  db[n] += sum_m dY[m, n]   (bias gradients)
-// One block handles a 64-row slab x 256 columns; fp32 atomics into db.
-template <typename T> __global__ void colsum_kernel(const T* __restrict__ dy, float* __restrict__ db, long M, int N, long ld, int rows_per_block) {
-    int col = blockIdx.x * blockDim.x + threadIdx.x;
-    long r0 = (long)blockIdx.y * rows_per_block;
-    long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-    if (col >= N) return;
+// Block = 64 columns x 4 row phases over a slab of rows; LDS combine, one fp32 atomic per column per block.
+template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, float* __restrict__ db, long M, int N, long ld, int rows_per_block) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
     float s = 0.f;
-    for (long r = r0; r < r1; ++r) s += to_f32(dy[r * ld + col]);
-    atomicAdd(&db[col], s);
+    if (col < N)
+        for (long r = r0 + ph; r < r1; r += 4) s += to_f32(dy[r * ld + col]);
+    red[ph][cl] = s;
+    __syncthreads();
+    if (ph == 0 && col < N) atomicAdd(&db[col], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
 
 // ---------------------------------------------------------------- fused Adam over one flat buffer
@@ -187,7 +206,7 @@ extern "C" int omr_dropout(int dtype, const void* x, void* out, long n, float p,
     if (p < 0.f || p >= 1.f) return OMR_ERR_ARG;
     uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
     float scale = 1.f / (1.f - p);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), ew_grid(n), EW_BLOCK, 0, (hipStream_t)stream, (const T*)x, (T*)out, n, thresh, scale,
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), ew_grid(n / Frag<T>::N + 1), EW_BLOCK, 0, (hipStream_t)stream, (const T*)x, (T*)out, n, thresh, scale,
                                          (uint64_t)seed, channel_mode, per_sample, C));
     OMR_CHECK_LAUNCH();
     return OMR_OK;
@@ -220,8 +239,8 @@ extern "C" int omr_add_pe2d(int dtype, const void* x, const float* pe_hwc, void*
 
 extern "C" int omr_colsum(int dtype, const void* dy, float* db, long M, int N, long ld, void* stream) {
     if (M <= 0 || N <= 0) return OMR_ERR_ARG;
-    int rpb = 256;
-    dim3 grid(cdiv(N, 256), cdiv(M, rpb));
+    int rpb = 128;
+    dim3 grid(cdiv(N, 64), cdiv(M, rpb));
     DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, 256, 0, (hipStream_t)stream, (const T*)dy, db, M, N, ld, rpb));
     OMR_CHECK_LAUNCH();
     return OMR_OK;

@@ -11,30 +11,58 @@ namespace {
 // Stage 1: each block reduces a slab of pixels for all channels; per-thread fp32 partials over a
 // short run, then fp64 atomics into ws[b][c][2] (sum, sum of squares).  Stage 2 finalises.
 // The apply is fused into the consumer's tile load (conv3 / depthwise conv3), never materialised.
-template <typename T>
-__global__ void instnorm_partial_kernel(const T* __restrict__ x, double* __restrict__ ws, long HW, int C, int pix_per_block) {
+// Thread t owns channel group (t % (C/VEC)) and walks pixels with 16-byte loads (fully coalesced: NHWC rows are
+// contiguous).  Per-thread fp32 partials over a short run -> LDS fp32 per-block sums -> one fp64 atomic per channel.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void instnorm_partial_kernel(const T* __restrict__ x, const T* __restrict__ g, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, double* __restrict__ ws, long HW, int C,
+                                                               int pix_per_block) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [C][2]
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
     const int b = blockIdx.y;
+    const int ncg = C / VEC;                       // channel groups; divides blockDim for the encoder's widths
+    const int cg = threadIdx.x % ncg, phase = threadIdx.x / ncg, nphase = blockDim.x / ncg;
     const long p0 = (long)blockIdx.x * pix_per_block;
     const long p1 = p0 + pix_per_block < HW ? p0 + pix_per_block : HW;
-    const T* xb = x + (long)b * HW * C;
-    // thread -> (channel, pixel phase): consecutive threads take consecutive channels (coalesced)
-    const bool wide = (int)blockDim.x >= C;            // several pixel phases per channel
-    const int cstride = wide ? C : (int)blockDim.x;
-    const int nphase = wide ? (int)blockDim.x / C : 1;
-    const int phase = wide ? (int)threadIdx.x / C : 0;
-    if (phase >= nphase) return;
-    for (int c = threadIdx.x % cstride; c < C; c += cstride) {
-        double s = 0.0, q = 0.0;
-        float fs = 0.f, fq = 0.f; int run = 0;
-        for (long p = p0 + phase; p < p1; p += nphase) {
-            float v = to_f32(xb[p * C + c]);
-            fs += v; fq += v * v;
-            if (++run == 32) { s += fs; q += fq; fs = fq = 0.f; run = 0; }
-        }
-        s += fs; q += fq;
-        atomicAdd(&ws[((long)b * C + c) * 2 + 0], s);
-        atomicAdd(&ws[((long)b * C + c) * 2 + 1], q);
+    const long base = (long)b * HW * C;
+    float s[VEC], q[VEC], mu[VEC], rs[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        s[e] = q[e] = 0.f;
+        mu[e] = BWD ? mean[(long)b * C + cg * VEC + e] : 0.f;
+        rs[e] = BWD ? rstd[(long)b * C + cg * VEC + e] : 1.f;
     }
+    if (phase < nphase) {
+        for (long p = p0 + phase; p < p1; p += nphase) {
+            const F xv = *reinterpret_cast<const F*>(x + base + p * C + cg * VEC);
+            if (BWD) {
+                const F gv = *reinterpret_cast<const F*>(g + base + p * C + cg * VEC);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float gg = to_f32(gv[e]);
+                    s[e] += gg;
+                    q[e] += gg * ((to_f32(xv[e]) - mu[e]) * rs[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float v = to_f32(xv[e]);
+                    s[e] += v;
+                    q[e] += v * v;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            atomicAdd(&red[(cg * VEC + e) * 2 + 0], s[e]);
+            atomicAdd(&red[(cg * VEC + e) * 2 + 1], q[e]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&ws[(long)b * C * 2 + i], (double)red[i]);
 }
 __global__ void instnorm_finalize_kernel(const double* __restrict__ ws, float* __restrict__ mean, float* __restrict__ rstd, long n, double inv_hw, float eps) {
     long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -51,47 +79,30 @@ __global__ void instnorm_finalize_kernel(const double* __restrict__ ws, float* _
 // Stage 1 accumulates sum(g), sum(g*xhat) per (b,c) in fp64; stage 2 applies, and optionally folds
 // in the ReLU(+dropout) backward of the producer of x: dx *= (x > 0) * relu_scale.
 template <typename T>
-__global__ void instnorm_bwd_partial_kernel(const T* __restrict__ g, const T* __restrict__ x, const float* __restrict__ mean,
-                                            const float* __restrict__ rstd, double* __restrict__ ws, long HW, int C, int pix_per_block) {
-    const int b = blockIdx.y;
-    const long p0 = (long)blockIdx.x * pix_per_block;
-    const long p1 = p0 + pix_per_block < HW ? p0 + pix_per_block : HW;
-    const long base = (long)b * HW * C;
-    const bool wide = (int)blockDim.x >= C;            // several pixel phases per channel
-    const int cstride = wide ? C : (int)blockDim.x;
-    const int nphase = wide ? (int)blockDim.x / C : 1;
-    const int phase = wide ? (int)threadIdx.x / C : 0;
-    if (phase >= nphase) return;
-    for (int c = threadIdx.x % cstride; c < C; c += cstride) {
-        const float mu = mean[(long)b * C + c], rs = rstd[(long)b * C + c];
-        double s = 0.0, q = 0.0;
-        float fs = 0.f, fq = 0.f; int run = 0;
-        for (long p = p0 + phase; p < p1; p += nphase) {
-            float gv = to_f32(g[base + p * C + c]);
-            float xh = (to_f32(x[base + p * C + c]) - mu) * rs;
-            fs += gv; fq += gv * xh;
-            if (++run == 32) { s += fs; q += fq; fs = fq = 0.f; run = 0; }
-        }
-        s += fs; q += fq;
-        atomicAdd(&ws[((long)b * C + c) * 2 + 0], s);
-        atomicAdd(&ws[((long)b * C + c) * 2 + 1], q);
-    }
-}
-template <typename T>
 __global__ void instnorm_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ x, const float* __restrict__ mean,
                                           const float* __restrict__ rstd, const double* __restrict__ ws, T* __restrict__ dx, long HW, int C,
                                           long total, float inv_hw, int relu_mask, float relu_scale) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % C);
-        long b = i / (HW * C);
-        long bc = b * C + c;
-        float mu = mean[bc], rs = rstd[bc];
-        float xv = to_f32(x[i]);
-        float xh = (xv - mu) * rs;
-        float s1 = (float)(ws[2 * bc] * inv_hw), s2 = (float)(ws[2 * bc + 1] * inv_hw);
-        float d = rs * (to_f32(g[i]) - s1 - xh * s2);
-        if (relu_mask) d = xv > 0.f ? d * relu_scale : 0.f;
-        dx[i] = from_f32<T>(d);
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N;
+    const long nvec = total / VEC;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const long e0 = i * VEC;
+        const int c = (int)(e0 % C);
+        const long b = e0 / (HW * C);
+        const F gv = reinterpret_cast<const F*>(g)[i], xv = reinterpret_cast<const F*>(x)[i];
+        F o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const long bc = b * C + c + e;
+            const float mu = mean[bc], rs = rstd[bc];
+            const float xf = to_f32(xv[e]);
+            const float xh = (xf - mu) * rs;
+            const float s1 = (float)(ws[2 * bc] * inv_hw), s2 = (float)(ws[2 * bc + 1] * inv_hw);
+            float d = rs * (to_f32(gv[e]) - s1 - xh * s2);
+            if (relu_mask) d = xf > 0.f ? d * relu_scale : 0.f;
+            o[e] = from_f32<T>(d);
+        }
+        reinterpret_cast<F*>(dx)[i] = o;
     }
 }
 
@@ -198,9 +209,12 @@ extern "C" int omr_instnorm_stats(int dtype, const void* x, float* mean, float* 
     if (B <= 0 || HW <= 0 || C <= 0 || !workspace) return OMR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(workspace, 0, omr_instnorm_workspace_bytes(B, C), s) != hipSuccess) return OMR_ERR_LAUNCH;
-    int ppb = 512;
+    const int vec = dtype == OMR_BF16 ? 8 : 4;
+    if (C % vec || 256 % (C / vec)) return OMR_ERR_UNSUPPORTED;
+    int ppb = 2048;
     dim3 grid(cdiv(HW, ppb), B);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_partial_kernel<T>), grid, 256, 0, s, (const T*)x, (double*)workspace, HW, C, ppb));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_partial_kernel<T, false>), grid, 256, 2 * C * sizeof(float), s, (const T*)x, (const T*)nullptr,
+                                         (const float*)nullptr, (const float*)nullptr, (double*)workspace, HW, C, ppb));
     long n = (long)B * C;
     hipLaunchKernelGGL(instnorm_finalize_kernel, cdiv(n, 256), 256, 0, s, (const double*)workspace, mean, rstd, n, 1.0 / (double)HW, eps);
     OMR_CHECK_LAUNCH();
@@ -212,12 +226,14 @@ extern "C" int omr_instnorm_bwd(int dtype, const void* dxhat, const void* x, con
     if (B <= 0 || HW <= 0 || C <= 0 || !workspace) return OMR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(workspace, 0, omr_instnorm_workspace_bytes(B, C), s) != hipSuccess) return OMR_ERR_LAUNCH;
-    int ppb = 512;
+    const int vec = dtype == OMR_BF16 ? 8 : 4;
+    if (C % vec || 256 % (C / vec)) return OMR_ERR_UNSUPPORTED;
+    int ppb = 2048;
     dim3 grid(cdiv(HW, ppb), B);
     long total = (long)B * HW * C;
-    long g2 = (total + 255) / 256; if (g2 > 4096) g2 = 4096;
+    long g2 = (total / vec + 255) / 256; if (g2 > 8192) g2 = 8192; if (g2 < 1) g2 = 1;
     DISPATCH_T(dtype, {
-        hipLaunchKernelGGL((instnorm_bwd_partial_kernel<T>), grid, 256, 0, s, (const T*)dxhat, (const T*)x, mean, rstd, (double*)workspace, HW, C, ppb);
+        hipLaunchKernelGGL((instnorm_partial_kernel<T, true>), grid, 256, 2 * C * sizeof(float), s, (const T*)x, (const T*)dxhat, mean, rstd, (double*)workspace, HW, C, ppb);
         hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), (int)g2, 256, 0, s, (const T*)dxhat, (const T*)x, mean, rstd, (const double*)workspace,
                            (T*)dx, HW, C, total, (float)(1.0 / (double)HW), relu_mask, relu_scale);
     });

@@ -60,9 +60,7 @@ class Conv3x3Fn(Function):
         g = gy.contiguous()
         if relu and mask_own:
             g = K.relu_bwd(g, y)
-        cout = g.shape[-1]
-        K.colsum_into(g.view(-1, cout), bias.omr_grad)
-        K.conv3x3_wgrad(x, g, weight.omr_grad, stride=stride, in_stats=stats)
+        K.conv3x3_wgrad(x, g, weight.omr_grad, stride=stride, in_stats=stats, db=bias.omr_grad)
         dx = None
         if ctx.needs_input_grad[0]:
             wd = K.conv3x3_weight_flip(wt(weight, x.dtype))

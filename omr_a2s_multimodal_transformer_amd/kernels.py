@@ -231,16 +231,18 @@ def conv3x3_weight_flip(w_phys: Tensor) -> Tensor:
     return wd
 
 
-def conv3x3_wgrad(x: Tensor, dy: Tensor, dw_phys: Tensor, stride=(1, 1), in_stats=None) -> None:
-    """dw_phys (fp32 [COUT,3,3,CIN], accumulated in place) += grad."""
-    require_cuda(x, dy, dw_phys)
+def conv3x3_wgrad(x: Tensor, dy: Tensor, dw_phys: Tensor, stride=(1, 1), in_stats=None, db: Optional[Tensor] = None) -> None:
+    """dw_phys (fp32 [COUT,3,3,CIN], accumulated in place) += grad; db (fp32 [COUT]) += bias grad (same pass over dy)."""
+    require_cuda(x, dy, dw_phys, db)
+    if db is not None:
+        assert db.dtype == torch.float32 and db.numel() == dy.shape[-1]
     B, H, W, CIN = x.shape
     _, Ho, Wo, COUT = dy.shape
     assert (Ho, Wo) == conv_out_hw(H, W, stride) and dy.shape[0] == B
     assert dw_phys.dtype == torch.float32 and dw_phys.is_contiguous() and tuple(dw_phys.shape) == (COUT, 3, 3, CIN)
     assert x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype
     mean, rstd = in_stats if in_stats is not None else (None, None)
-    lib().call("omr_conv3x3_wgrad", dtype_code(x.dtype), ptr(x), ptr(dy), ptr(dw_phys), ptr(mean), ptr(rstd), B, H, W, CIN, COUT, stride[0], stride[1],
+    lib().call("omr_conv3x3_wgrad", dtype_code(x.dtype), ptr(x), ptr(dy), ptr(dw_phys), ptr(db), ptr(mean), ptr(rstd), B, H, W, CIN, COUT, stride[0], stride[1],
                Ho, Wo, cur_stream())
 
 
