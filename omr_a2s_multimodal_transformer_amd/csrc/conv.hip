@@ -10,12 +10,39 @@
 //   conv3x3_wgrad    dW[n][tap][c] += sum_pix dY[pix][n] X[pix+tap][c]  (MFMA, K = pixels, fp32 atomics)
 //   conv1_direct     the 1 -> 16 first layer (K = 9: HBM-bound, VALU) forward and weight gradient
 //   dwconv3x3        depthwise 3x3 forward / data gradient / weight gradient (HBM-bound, VALU)
+#include <type_traits>
+
 #include "omr_common.h"
 #include "omr_hip.h"
 
 namespace {
 
 constexpr int TW = 32;  // output tile width = one MFMA M-block (32 pixels of one output row)
+
+// Walk tile pixels pix = pix0 + k*DP (k = 0, 1, ...) keeping an incremental (row, col) inside a tile of width IW, in
+// batches of G: all G global loads are issued before the first LDS store so their latencies overlap (a plain
+// load->store loop serialises on s_waitcnt vmcnt(0) every iteration).
+template <int G, typename F, typename LoadFn, typename StoreFn>
+__device__ __forceinline__ void staged_walk(int pix0, int npix, int DP, int il0, int jl0, int di, int dj, int IW, LoadFn load, StoreFn store) {
+    int il = il0, jl = jl0;
+    for (int base = pix0; base < npix; base += G * DP) {
+        F v[G];
+        int pix = base;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (pix < npix) v[g] = load(il, jl);
+            jl += dj; il += di;
+            if (jl >= IW) { jl -= IW; ++il; }
+            pix += DP;
+        }
+        pix = base;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (pix < npix) store(pix, v[g]);
+            pix += DP;
+        }
+    }
+}
 
 struct ConvArgs {
     const void* x; const void* w; const float* bias; void* y;
@@ -59,37 +86,53 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
 
     const int frow = lane & 31, fk = (lane >> 5) * VEC;
     constexpr int CPP = CK / VEC;  // 16-byte chunks per pixel per channel chunk
+    // staging walks the halo with a fixed per-thread channel chunk and an incremental (row, col): no divisions in the loop
+    constexpr int DP = 256 / CPP;                 // halo pixels advanced per iteration
+    const int di = DP / IW, dj = DP % IW;
+    const int pix0 = tid / CPP, kc0 = (tid % CPP) * VEC;
+    const int il0 = pix0 / IW, jl0 = pix0 % IW;
+    const int mh = a.dh - 1, mw = a.dw - 1, shh = a.dh >> 1, shw = a.dw >> 1;   // dilation is 1 or 2
+    const int npix = IH * IW;
 
     for (int c0 = 0; c0 < a.CIN; c0 += CK) {
         __syncthreads();
         // ---- stage the input halo (zero outside the image and on dilation holes)
-        const int nx = IH * IW * CPP;
-        for (int c = tid; c < nx; c += 256) {
-            const int pix = c / CPP, kc = (c % CPP) * VEC;
-            const int il = pix / IW, jl = pix % IW;
-            const int vh = vh0 + il, vw = vw0 + jl;
-            F v = frag_zero<T>();
-            if (vh >= 0 && vh < Hv && vw >= 0 && vw < Wv && (vh % a.dh) == 0 && (vw % a.dw) == 0) {
-                const int ih = vh / a.dh, iw = vw / a.dw;
-                v = *reinterpret_cast<const F*>(X + ((long)ih * a.Wr + iw) * a.CIN + c0 + kc);
-                if (a.mean) {
+        staged_walk<6, F>(pix0, npix, DP, il0, jl0, di, dj, IW,
+            [&](int il, int jl) -> F {
+                const int vh = vh0 + il, vw = vw0 + jl;
+                F v = frag_zero<T>();
+                if (vh >= 0 && vh < Hv && vw >= 0 && vw < Wv && (vh & mh) == 0 && (vw & mw) == 0) {
+                    const int ih = vh >> shh, iw = vw >> shw;
+                    v = *reinterpret_cast<const F*>(X + ((long)ih * a.Wr + iw) * a.CIN + c0 + kc0);
+                    if (a.mean) {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const int ch = b * a.CIN + c0 + kc + e;
-                        v[e] = from_f32<T>((to_f32(v[e]) - a.mean[ch]) * a.rstd[ch]);
+                        for (int e = 0; e < VEC; ++e) {
+                            const int ch = b * a.CIN + c0 + kc0 + e;
+                            v[e] = from_f32<T>((to_f32(v[e]) - a.mean[ch]) * a.rstd[ch]);
+                        }
                     }
                 }
+                return v;
+            },
+            [&](int pix, const F& v) { *reinterpret_cast<F*>(Xs + (long)pix * CKP + kc0) = v; });
+        // ---- stage the weights of this channel chunk: Ws[n][tap][k]  (rows = n*9 + tap; batched loads)
+        {
+            constexpr int NROW = NT * 9, GW = 5;
+            for (int base = pix0; base < NROW; base += GW * DP) {
+                F v[GW];
+#pragma unroll
+                for (int g = 0; g < GW; ++g) {
+                    const int row = base + g * DP;
+                    const int n = n0 + row / 9;
+                    v[g] = frag_zero<T>();
+                    if (row < NROW && n < a.COUT) v[g] = *reinterpret_cast<const F*>(W + ((long)n * 9 + row % 9) * a.CIN + c0 + kc0);
+                }
+#pragma unroll
+                for (int g = 0; g < GW; ++g) {
+                    const int row = base + g * DP;
+                    if (row < NROW) *reinterpret_cast<F*>(Ws + (long)row * CKP + kc0) = v[g];
+                }
             }
-            *reinterpret_cast<F*>(Xs + (long)pix * CKP + kc) = v;
-        }
-        // ---- stage the weights of this channel chunk: Ws[n][tap][k]
-        const int nw = NT * 9 * CPP;
-        for (int c = tid; c < nw; c += 256) {
-            const int row = c / CPP, kc = (c % CPP) * VEC;  // row = n*9 + tap
-            const int n = n0 + row / 9;
-            F v = frag_zero<T>();
-            if (n < a.COUT) v = *reinterpret_cast<const F*>(W + ((long)n * 9 + row % 9) * a.CIN + c0 + kc);
-            *reinterpret_cast<F*>(Ws + (long)row * CKP + kc) = v;
         }
         __syncthreads();
         // ---- nine shifted GEMMs out of LDS
@@ -116,29 +159,39 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
         }
     }
 
-    // ---- epilogue: bias, ReLU, optional mask; lanes 0..31 write 32 consecutive couts of one pixel
-    T* Y = (T*)a.y + (long)b * a.Ho * a.Wo * a.COUT;
-    const T* Mk = a.mask ? (const T*)a.mask + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
+    // ---- epilogue: bias + ReLU in registers, tile staged through LDS, then 16-byte coalesced stores (+ optional mask)
+    __syncthreads();                              // every wave is done with Xs / Ws: reuse the space
+    constexpr int OP = NT + VEC;                  // output-tile pitch (elements)
+    T* Os = reinterpret_cast<T*>(smem_raw);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int n = n0 + j * 32 + (lane & 31);
-        if (n >= a.COUT) continue;
-        const float bv = a.bias ? a.bias[n] : 0.f;
+        const int nl = j * 32 + (lane & 31);
+        const float bv = (a.bias && n0 + nl < a.COUT) ? a.bias[n0 + nl] : 0.f;
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int oh = oh0 + wave * RPW + i;
-            if (oh >= a.Ho) continue;
+        for (int i = 0; i < RPW; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ow = ow0 + acc_row(r, lane);
-                if (ow >= a.Wo) continue;
                 float v = acc[i][j][r] + bv;
                 if (a.relu) v = fmaxf(v, 0.f);
-                const long o = ((long)oh * a.Wo + ow) * a.COUT + n;
-                if (Mk) v = to_f32(Mk[o]) > 0.f ? v * a.mask_scale : 0.f;
-                Y[o] = from_f32<T>(v);
+                Os[(long)((wave * RPW + i) * TW + acc_row(r, lane)) * OP + nl] = from_f32<T>(v);
             }
+    }
+    __syncthreads();
+    T* Y = (T*)a.y + (long)b * a.Ho * a.Wo * a.COUT;
+    const T* Mk = a.mask ? (const T*)a.mask + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
+    constexpr int CPO = NT / VEC;
+    for (int c = tid; c < TH * TW * CPO; c += 256) {
+        const int pl = c / CPO, kc = (c % CPO) * VEC;
+        const int oh = oh0 + pl / TW, ow = ow0 + pl % TW, n = n0 + kc;
+        if (oh >= a.Ho || ow >= a.Wo || n >= a.COUT) continue;
+        F v = *reinterpret_cast<const F*>(Os + (long)pl * OP + kc);
+        const long o = ((long)oh * a.Wo + ow) * a.COUT + n;
+        if (Mk) {
+            const F m = *reinterpret_cast<const F*>(Mk + o);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = from_f32<T>(to_f32(m[e]) > 0.f ? to_f32(v[e]) * a.mask_scale : 0.f);
         }
+        *reinterpret_cast<F*>(Y + o) = v;
     }
 }
 
@@ -150,7 +203,10 @@ template <typename T, int NT, int RPW, int CK> int launch_conv(const ConvArgs& a
     a.tiles_h = cdiv(a.Ho, TH);
     const int IH = (TH - 1) * a.sh + 3, IW = (TW - 1) * a.sw + 3;
     size_t shm = ((size_t)IH * IW + (size_t)NT * 9) * CKP * sizeof(T);
+    const size_t shm_out = (size_t)TH * TW * (NT + Frag<T>::N) * sizeof(T);   // epilogue staging reuses the same space
+    if (shm_out > shm) shm = shm_out;
     if (shm > 160 * 1024) return OMR_ERR_UNSUPPORTED;
+    if (a.COUT % Frag<T>::N) return OMR_ERR_UNSUPPORTED;
     auto kern = conv3x3_mfma_kernel<T, NT, RPW, CK>;
     if (shm > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return OMR_ERR_LAUNCH;
@@ -203,7 +259,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     typedef typename Frag<T>::type F;
     constexpr int VEC = Frag<T>::N;
     constexpr int WN = CBN / 32, WC = CBC / 32, WK = 4 / (WN * WC);   // waves over couts, cins and pixel slices
-    constexpr int NP = CBN + 2, CP = CBC + 2;   // LDS pitches (elements)
+    constexpr bool TR = std::is_same<T, bf16>::value;       // bf16: transposing LDS reads; fp32: element gathers
+    // LDS pitches (elements).  tr path: 4 consecutive pixel rows x 16 dwords must tile the 64 banks -> 64 B rows for 32
+    // channels, 192 B rows for 64 channels (conflict-free for unit pixel stride); scalar path: odd dword pitch.
+    constexpr int NP = TR ? (CBN == 32 ? 32 : 96) : CBN + 4, CP = TR ? (CBC == 32 ? 32 : 96) : CBC + 4;
+    typedef __attribute__((address_space(3))) bf16x4 LdsV4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int IH = (TH - 1) * a.sh + 3, IW = (TW - 1) * a.sw + 3;
     T* Ys = reinterpret_cast<T*>(smem_raw);            // [TH*TW][NP]
@@ -220,6 +280,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    const int dix = (256 / (CBC / VEC)) / IW, djx = (256 / (CBC / VEC)) % IW;   // halo staging increments (pixels per pass)
+    const int il0x = (tid / (CBC / VEC)) / IW, jl0x = (tid / (CBC / VEC)) % IW;
     const int ntiles = a.B * a.tiles_h * a.tiles_w;
     const bool do_bias = a.db != nullptr && (blockIdx.y % ncb) == 0;   // one cin-block column of the grid owns the bias sums
     float bsum = 0.f;
@@ -231,30 +293,39 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
         const T* X = (const T*)a.x + (long)b * a.Hr * a.Wr * a.CIN;
         const T* DY = (const T*)a.dy + (long)b * a.Ho * a.Wo * a.COUT;
         __syncthreads();
-        for (int c = tid; c < TH * TW * (CBN / VEC); c += 256) {
-            const int pix = c / (CBN / VEC), kc = (c % (CBN / VEC)) * VEC;
-            const int oh = oh0 + pix / TW, ow = ow0 + pix % TW;
-            F v = frag_zero<T>();
-            if (oh < a.Ho && ow < a.Wo && n0 + kc < a.COUT) v = *reinterpret_cast<const F*>(DY + ((long)oh * a.Wo + ow) * a.COUT + n0 + kc);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) Ys[(long)pix * NP + kc + e] = v[e];
+        // ---- stage dY tile [pix][CBN] and X halo [pix][CBC] (batched 16-byte loads, incremental indices)
+        {
+            constexpr int CPN = CBN / VEC, DPN = 256 / CPN;
+            const int kc = (tid % CPN) * VEC;
+            staged_walk<4, F>(tid / CPN, TH * TW, DPN, (tid / CPN) / TW, (tid / CPN) % TW, DPN / TW, DPN % TW, TW,
+                [&](int il, int jl) -> F {
+                    const int oh = oh0 + il, ow = ow0 + jl;
+                    F v = frag_zero<T>();
+                    if (oh < a.Ho && ow < a.Wo && n0 + kc < a.COUT) v = *reinterpret_cast<const F*>(DY + ((long)oh * a.Wo + ow) * a.COUT + n0 + kc);
+                    return v;
+                },
+                [&](int pix, const F& v) { *reinterpret_cast<F*>(Ys + (long)pix * NP + kc) = v; });
         }
-        for (int c = tid; c < IH * IW * (CBC / VEC); c += 256) {
-            const int pix = c / (CBC / VEC), kc = (c % (CBC / VEC)) * VEC;
-            const int ih = ih0 + pix / IW, iw = iw0 + pix % IW;
-            F v = frag_zero<T>();
-            if (ih >= 0 && ih < a.Hr && iw >= 0 && iw < a.Wr && c0 + kc < a.CIN) {
-                v = *reinterpret_cast<const F*>(X + ((long)ih * a.Wr + iw) * a.CIN + c0 + kc);
-                if (a.mean) {
+        {
+            constexpr int CPC = CBC / VEC, DPC = 256 / CPC;
+            const int kc = (tid % CPC) * VEC;
+            staged_walk<6, F>(tid / CPC, IH * IW, DPC, il0x, jl0x, dix, djx, IW,
+                [&](int il, int jl) -> F {
+                    const int ih = ih0 + il, iw = iw0 + jl;
+                    F v = frag_zero<T>();
+                    if (ih >= 0 && ih < a.Hr && iw >= 0 && iw < a.Wr && c0 + kc < a.CIN) {
+                        v = *reinterpret_cast<const F*>(X + ((long)ih * a.Wr + iw) * a.CIN + c0 + kc);
+                        if (a.mean) {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const int ch = b * a.CIN + c0 + kc + e;
-                        v[e] = from_f32<T>((to_f32(v[e]) - a.mean[ch]) * a.rstd[ch]);
+                            for (int e = 0; e < VEC; ++e) {
+                                const int ch = b * a.CIN + c0 + kc + e;
+                                v[e] = from_f32<T>((to_f32(v[e]) - a.mean[ch]) * a.rstd[ch]);
+                            }
+                        }
                     }
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) Xs[(long)pix * CP + kc + e] = v[e];
+                    return v;
+                },
+                [&](int pix, const F& v) { *reinterpret_cast<F*>(Xs + (long)pix * CP + kc) = v; });
         }
         __syncthreads();
         if (do_bias) {   // bias gradient: column sums of the staged dY tile (thread = channel x pixel phase)
@@ -262,20 +333,44 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
             const int ch = tid % CBN;
             for (int pix = tid / CBN; pix < TH * TW; pix += NPH) bsum += to_f32(Ys[(long)pix * NP + ch]);
         }
-        const int nl = wn * 32 + (lane & 31), cl = wc * 32 + (lane & 31);
-        for (int k0 = wk * KStep<T>::value; k0 < TH * TW; k0 += WK * KStep<T>::value) {
-            const int pbase = k0 + (lane >> 5) * VEC;     // VEC consecutive pixels of one tile row
-            const int r = pbase / TW, col = pbase % TW;
-            F af;
+        if constexpr (TR) {
+            // bf16: k-major operand fragments straight out of the [pixel][channel] tiles with ds_read_b64_tr_b16.
+            // Lane (q, p, cb, h) supplies the address of pixel row q, channels 16cb+4p.. of its 16-lane group's 4x16 block
+            // and receives 4 consecutive pixels of channel 16cb + (lane & 15) (verified on hardware, scratch/trtest.hip).
+            const int q = (lane & 15) >> 2, chan = ((lane >> 4) & 1) * 16 + (lane & 3) * 4, hh = lane >> 5;
+            for (int k0 = wk * 16; k0 < TH * TW; k0 += WK * 16) {
+                const int pk = k0 + 8 * hh + q;                // u = 0 block; the u = 1 block is 4 pixels further (same tile row)
+                const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(Ys + (long)pk * NP + wn * 32 + chan));
+                const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(Ys + (long)(pk + 4) * NP + wn * 32 + chan));
+                const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                const int r = pk >> 5, col = pk & 31;
+                const T* xrow = Xs + (long)((r * a.sh) * IW + col * a.sw) * CP + wc * 32 + chan;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) af[e] = Ys[(long)(pbase + e) * NP + nl];
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int kh = tap / 3, kw = tap % 3;
+                    const T* xp = xrow + (long)(kh * IW + kw) * CP;
+                    const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)xp);
+                    const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(xp + (long)4 * a.sw * CP));
+                    const bf16x8 bf = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    mma32(acc[tap], af, bf);
+                }
+            }
+        } else {
+            const int nl = wn * 32 + (lane & 31), cl = wc * 32 + (lane & 31);
+            for (int k0 = wk * KStep<T>::value; k0 < TH * TW; k0 += WK * KStep<T>::value) {
+                const int pbase = k0 + (lane >> 5) * VEC;     // VEC consecutive pixels of one tile row
+                const int r = pbase / TW, col = pbase % TW;
+                F af;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int kh = tap / 3, kw = tap % 3;
-                F bf;
+                for (int e = 0; e < VEC; ++e) af[e] = Ys[(long)(pbase + e) * NP + nl];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) bf[e] = Xs[(long)((r * a.sh + kh) * IW + (col + e) * a.sw + kw) * CP + cl];
-                mma32(acc[tap], af, bf);
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int kh = tap / 3, kw = tap % 3;
+                    F bf;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) bf[e] = Xs[(long)((r * a.sh + kh) * IW + (col + e) * a.sw + kw) * CP + cl];
+                    mma32(acc[tap], af, bf);
+                }
             }
         }
     }
@@ -300,7 +395,9 @@ template <typename T, int TH, int CBN, int CBC> int launch_wgrad2(WgradArgs a, h
     a.tiles_w = cdiv(a.Wo, TW);
     a.tiles_h = cdiv(a.Ho, TH);
     const int IH = (TH - 1) * a.sh + 3, IW = (TW - 1) * a.sw + 3;
-    size_t shm = ((size_t)TH * TW * (CBN + 2) + (size_t)IH * IW * (CBC + 2)) * sizeof(T);
+    constexpr bool TR = std::is_same<T, bf16>::value;
+    constexpr int NP = TR ? (CBN == 32 ? 32 : 96) : CBN + 4, CP = TR ? (CBC == 32 ? 32 : 96) : CBC + 4;
+    size_t shm = ((size_t)TH * TW * NP + (size_t)IH * IW * CP) * sizeof(T);
     if (shm > 160 * 1024) return OMR_ERR_UNSUPPORTED;
     auto kern = conv3x3_wgrad_kernel<T, TH, CBN, CBC>;
     if (shm > 48 * 1024) {
@@ -392,31 +489,43 @@ __global__ void conv1_wgrad_kernel(const T* __restrict__ x, const T* __restrict_
 // one pixel x VEC channels.  flip=1 applies the taps mirrored (data gradient).  Optional fused
 // InstanceNorm apply on the input and optional epilogue mask (ReLU/dropout backward of the producer).
 template <typename T>
-__global__ void dwconv3x3_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y,
-                                 const float* __restrict__ mean, const float* __restrict__ rstd, const T* __restrict__ mask, float mask_scale,
-                                 int B, int H, int Wd, int C, int flip) {
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd, const T* __restrict__ mask, float mask_scale,
+                                                        int B, int H, int Wd, int C, int flip) {
     typedef typename Frag<T>::type F;
     constexpr int VEC = Frag<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [9][C] taps (already mirrored when flip) + [C] bias
+    for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) {
+        const int t = i / C, c = i % C;
+        wsm[i] = to_f32(w[c * 9 + (flip ? 8 - t : t)]);
+    }
+    for (int i = threadIdx.x; i < C; i += blockDim.x) wsm[9 * C + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
     const int cv = C / VEC;
     const long total = (long)B * H * Wd * cv;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % cv) * VEC; long p = i / cv;
         const int j = (int)(p % Wd); long q = p / Wd; const int ii = (int)(q % H); const long b = q / H;
+        F xv[9];
+        bool ok[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {          // issue all nine 16-byte loads before using any
+            const int yy = ii + t / 3 - 1, xx = j + t % 3 - 1;
+            ok[t] = yy >= 0 && yy < H && xx >= 0 && xx < Wd;
+            if (ok[t]) xv[t] = *reinterpret_cast<const F*>(x + ((b * H + yy) * Wd + xx) * C + c);
+        }
         float s[VEC], mu[VEC], rs[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            s[e] = bias ? bias[c + e] : 0.f;
+            s[e] = wsm[9 * C + c + e];
             mu[e] = mean ? mean[b * C + c + e] : 0.f;
             rs[e] = rstd ? rstd[b * C + c + e] : 1.f;
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int yy = ii + t / 3 - 1, xx = j + t % 3 - 1;
-            if (yy < 0 || yy >= H || xx < 0 || xx >= Wd) continue;
-            const F v = *reinterpret_cast<const F*>(x + ((b * H + yy) * Wd + xx) * C + c);
-            const int tw = flip ? 8 - t : t;
+            if (!ok[t]) continue;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) s[e] += to_f32(w[(c + e) * 9 + tw]) * ((to_f32(v[e]) - mu[e]) * rs[e]);
+            for (int e = 0; e < VEC; ++e) s[e] += wsm[t * C + c + e] * ((to_f32(xv[t][e]) - mu[e]) * rs[e]);
         }
         F o;
         if (mask) {
@@ -499,7 +608,7 @@ extern "C" int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const fl
                                const void* out_mask, float mask_scale, int B, int H, int W, int CIN, int COUT, int stride_h, int stride_w,
                                int dil_h, int dil_w, int Ho, int Wo, int relu, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0 || CIN <= 0 || COUT <= 0 || !x || !w || !y) return OMR_ERR_ARG;
-    if (stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1) return OMR_ERR_ARG;
+    if (stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1 || dil_h > 2 || dil_w > 2) return OMR_ERR_ARG;
     if ((stride_h > 1 || stride_w > 1) && (dil_h > 1 || dil_w > 1)) return OMR_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     if (CIN == 1) {
@@ -561,7 +670,8 @@ extern "C" int omr_dwconv3x3(int dtype, const void* x, const void* w, const floa
     const int vec = dtype == OMR_BF16 ? 8 : 4;
     if (C % vec) return OMR_ERR_UNSUPPORTED;
     long total = (long)B * H * W * (C / vec);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T>), ew_grid(total), 256, 0, (hipStream_t)stream, (const T*)x, (const T*)w, bias, (T*)y,
+    int grid = (int)((total + 1023) / 1024); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;   // >= 4 pixels x groups per thread amortise the weight staging
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T>), grid, 256, (size_t)10 * C * sizeof(float), (hipStream_t)stream, (const T*)x, (const T*)w, bias, (T*)y,
                                          in_mean, in_rstd, (const T*)out_mask, mask_scale, B, H, W, C, flip));
     OMR_CHECK_LAUNCH();
     return OMR_OK;
