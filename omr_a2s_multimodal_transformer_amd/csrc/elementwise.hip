@@ -53,27 +53,36 @@ template <typename T> __global__ void relu_bwd_kernel(const T* __restrict__ dy, 
 // ---------------------------------------------------------------- dropout (elementwise, or per (b, channel) for Dropout2d on NHWC)
 // out = keep ? x / (1-p) : 0.   channel_mode: the mask index is b*C + c (nn.Dropout2d zeroes whole
 // channels, encoder.py:99); otherwise the flat element index.
-template <typename T> __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ o, long n, uint32_t thresh, float scale,
-                                                     uint64_t seed, int channel_mode, long per_sample, int C) {
+template <typename T, bool CH> __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ o, long n, uint32_t thresh, float scale,
+                                                              uint64_t seed, long per_sample, int C) {
     typedef typename Vec<T>::type V;
     constexpr int N = Vec<T>::N;
-    const long nv = n / N;     // callers pass tensors whose channel count is a multiple of N (or tiny tails handled below)
+    if (CH) {
+        // one keep/drop decision per (sample, channel): blockIdx.y = sample, 32-bit index math inside the sample
+        const long sbase = (long)blockIdx.y * per_sample;
+        const uint32_t nv = (uint32_t)(per_sample / N);
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) {
+            const uint32_t c0 = (i * N) % (uint32_t)C;
+            const V v = reinterpret_cast<const V*>(x + sbase)[i];
+            V r;
+#pragma unroll
+            for (int e = 0; e < N; ++e)
+                r[e] = drop_keep(seed, (uint64_t)blockIdx.y * C + c0 + e, thresh) ? from_f32<T>(to_f32(v[e]) * scale) : from_f32<T>(0.f);
+            reinterpret_cast<V*>(o + sbase)[i] = r;
+        }
+        return;
+    }
+    const long nv = n / N;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
         const V v = reinterpret_cast<const V*>(x)[i];
         V r;
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-            const long k = i * N + e;
-            const uint64_t idx = channel_mode ? (uint64_t)((k / per_sample) * C + (k % C)) : (uint64_t)k;
-            r[e] = drop_keep(seed, idx, thresh) ? from_f32<T>(to_f32(v[e]) * scale) : from_f32<T>(0.f);
-        }
+        for (int e = 0; e < N; ++e) r[e] = drop_keep(seed, (uint64_t)(i * N + e), thresh) ? from_f32<T>(to_f32(v[e]) * scale) : from_f32<T>(0.f);
         reinterpret_cast<V*>(o)[i] = r;
     }
     if (blockIdx.x == 0)
-        for (long k = nv * N + threadIdx.x; k < n; k += blockDim.x) {
-            const uint64_t idx = channel_mode ? (uint64_t)((k / per_sample) * C + (k % C)) : (uint64_t)k;
-            o[k] = drop_keep(seed, idx, thresh) ? from_f32<T>(to_f32(x[k]) * scale) : from_f32<T>(0.f);
-        }
+        for (long k = nv * N + threadIdx.x; k < n; k += blockDim.x)
+            o[k] = drop_keep(seed, (uint64_t)k, thresh) ? from_f32<T>(to_f32(x[k]) * scale) : from_f32<T>(0.f);
 }
 
 // ---------------------------------------------------------------- embedding gather + 1-D positional encoding
@@ -206,8 +215,17 @@ extern "C" int omr_dropout(int dtype, const void* x, void* out, long n, float p,
     if (p < 0.f || p >= 1.f) return OMR_ERR_ARG;
     uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
     float scale = 1.f / (1.f - p);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), ew_grid(n / Frag<T>::N + 1), EW_BLOCK, 0, (hipStream_t)stream, (const T*)x, (T*)out, n, thresh, scale,
-                                         (uint64_t)seed, channel_mode, per_sample, C));
+    hipStream_t s = (hipStream_t)stream;
+    if (channel_mode) {
+        const int vec = dtype == OMR_BF16 ? 8 : 4;
+        if (per_sample <= 0 || n % per_sample || C % vec || per_sample % C || per_sample > 0x7fffffffL) return OMR_ERR_ARG;
+        const int B = (int)(n / per_sample);
+        dim3 grid(ew_grid(per_sample / vec) > 256 ? 256 : ew_grid(per_sample / vec), B);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T, true>), grid, EW_BLOCK, 0, s, (const T*)x, (T*)out, n, thresh, scale, (uint64_t)seed, per_sample, C));
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T, false>), ew_grid(n / Frag<T>::N + 1), EW_BLOCK, 0, s, (const T*)x, (T*)out, n, thresh, scale,
+                                             (uint64_t)seed, per_sample, C));
+    }
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }

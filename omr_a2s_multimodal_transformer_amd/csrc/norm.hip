@@ -78,31 +78,37 @@ __global__ void instnorm_finalize_kernel(const double* __restrict__ ws, float* _
 //   dx = rstd * (g - mean_hw(g) - xhat * mean_hw(g * xhat))
 // Stage 1 accumulates sum(g), sum(g*xhat) per (b,c) in fp64; stage 2 applies, and optionally folds
 // in the ReLU(+dropout) backward of the producer of x: dx *= (x > 0) * relu_scale.
+// Apply: thread owns one channel group (statistics loaded once into registers) and walks its pixels: no index divisions.
 template <typename T>
-__global__ void instnorm_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ x, const float* __restrict__ mean,
-                                          const float* __restrict__ rstd, const double* __restrict__ ws, T* __restrict__ dx, long HW, int C,
-                                          long total, float inv_hw, int relu_mask, float relu_scale) {
+__global__ __launch_bounds__(256) void instnorm_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ x, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const double* __restrict__ ws, T* __restrict__ dx, long HW,
+                                                                 int C, int pix_per_block, float inv_hw, int relu_mask, float relu_scale) {
     typedef typename Frag<T>::type F;
     constexpr int VEC = Frag<T>::N;
-    const long nvec = total / VEC;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-        const long e0 = i * VEC;
-        const int c = (int)(e0 % C);
-        const long b = e0 / (HW * C);
-        const F gv = reinterpret_cast<const F*>(g)[i], xv = reinterpret_cast<const F*>(x)[i];
+    const int b = blockIdx.y;
+    const int ncg = C / VEC;
+    const int cg = threadIdx.x % ncg, phase = threadIdx.x / ncg, nphase = blockDim.x / ncg;
+    float mu[VEC], rs[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const long bc = (long)b * C + cg * VEC + e;
+        mu[e] = mean[bc]; rs[e] = rstd[bc];
+        s1[e] = (float)(ws[2 * bc] * (double)inv_hw); s2[e] = (float)(ws[2 * bc + 1] * (double)inv_hw);
+    }
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    const long p1 = p0 + pix_per_block < HW ? p0 + pix_per_block : HW;
+    const long base = (long)b * HW * C + cg * VEC;
+    for (long p = p0 + phase; p < p1; p += nphase) {
+        const F gv = *reinterpret_cast<const F*>(g + base + p * C), xv = *reinterpret_cast<const F*>(x + base + p * C);
         F o;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const long bc = b * C + c + e;
-            const float mu = mean[bc], rs = rstd[bc];
             const float xf = to_f32(xv[e]);
-            const float xh = (xf - mu) * rs;
-            const float s1 = (float)(ws[2 * bc] * inv_hw), s2 = (float)(ws[2 * bc + 1] * inv_hw);
-            float d = rs * (to_f32(gv[e]) - s1 - xh * s2);
+            float d = rs[e] * (to_f32(gv[e]) - s1[e] - (xf - mu[e]) * rs[e] * s2[e]);
             if (relu_mask) d = xf > 0.f ? d * relu_scale : 0.f;
             o[e] = from_f32<T>(d);
         }
-        reinterpret_cast<F*>(dx)[i] = o;
+        *reinterpret_cast<F*>(dx + base + p * C) = o;
     }
 }
 
@@ -230,12 +236,12 @@ extern "C" int omr_instnorm_bwd(int dtype, const void* dxhat, const void* x, con
     if (C % vec || 256 % (C / vec)) return OMR_ERR_UNSUPPORTED;
     int ppb = 2048;
     dim3 grid(cdiv(HW, ppb), B);
-    long total = (long)B * HW * C;
-    long g2 = (total / vec + 255) / 256; if (g2 > 8192) g2 = 8192; if (g2 < 1) g2 = 1;
+    int ppb2 = 1024;
+    dim3 grid2(cdiv(HW, ppb2), B);
     DISPATCH_T(dtype, {
         hipLaunchKernelGGL((instnorm_partial_kernel<T, true>), grid, 256, 2 * C * sizeof(float), s, (const T*)x, (const T*)dxhat, mean, rstd, (double*)workspace, HW, C, ppb);
-        hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), (int)g2, 256, 0, s, (const T*)dxhat, (const T*)x, mean, rstd, (const double*)workspace,
-                           (T*)dx, HW, C, total, (float)(1.0 / (double)HW), relu_mask, relu_scale);
+        hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), grid2, 256, 0, s, (const T*)dxhat, (const T*)x, mean, rstd, (const double*)workspace,
+                           (T*)dx, HW, C, ppb2, (float)(1.0 / (double)HW), relu_mask, relu_scale);
     });
     OMR_CHECK_LAUNCH();
     return OMR_OK;

@@ -90,9 +90,18 @@ __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
     z = z ^ (z >> 31);
     return (uint32_t)(z >> 32);
 }
+// 32-bit variant (two rounds of a multiply-xorshift mixer keyed by both seed halves) for indices < 2^32:
+// ~10 VALU ops per element instead of ~30 for the 64-bit mixer.
+__device__ __forceinline__ uint32_t hash32(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx) {
+    uint32_t h = idx * 0x9E3779B1u + seed_lo;
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h += seed_hi; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
 // keep iff hash >= p * 2^32
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-    return hash_u32(seed, idx) >= thresh;
+    return hash32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)idx ^ (uint32_t)(idx >> 32) * 0x27D4EB2Fu) >= thresh;
 }
 
 __host__ __device__ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
