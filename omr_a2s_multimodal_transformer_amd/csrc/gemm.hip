@@ -9,6 +9,8 @@
 //   1x1 "point_conv" of DepthSepConv2D (encoder.py:65-70) on NHWC activations = the same GEMMs
 //   Conv1d(k=1) head (decoder.py:98-102)       = the same GEMM with N = vocabulary
 // Block tile 128x128, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 blocks; BK = 2 k-steps.
+#include <type_traits>
+
 #include "omr_common.h"
 #include "omr_hip.h"
 
@@ -18,6 +20,7 @@ struct GemmArgs {
     const void* A; const void* B; void* C; const float* bias;
     int M, N, K; long lda, ldb, ldc;
     int relu, accum, atomic, ksplit_len;
+    float* colsum_a;   // transA only: colsum_a[m] += sum_k A[k][m] (bias gradient of a linear layer), fused into the dW GEMM
 };
 
 constexpr int BM = 128, BN = 128;
@@ -27,7 +30,12 @@ template <typename T> struct GemmCfg {
     static constexpr int BK = 2 * KStep<T>::value;          // 32 (bf16) / 16 (fp32): 64 B per row
     static constexpr int PITCH = BK + VEC;                   // 80 B pitch: conflict-free b128 reads
     static constexpr int CHUNKS_PER_ROW = BK / VEC;          // 4
+    // reduction-major bf16 operands are staged as they lie in HBM ([k][128 rows]) and read with ds_read_b64_tr_b16:
+    // pitch = 16 dwords mod 64 so the 4 k-rows of a transposing read tile all 64 banks.
+    static constexpr int TPITCH = 128 + 32;
+    static constexpr int LDS_ELEMS = (BM * PITCH > BK * TPITCH) ? BM * PITCH : BK * TPITCH;
 };
+template <typename T, bool TR> struct UseTrRead { static constexpr bool value = TR && std::is_same<T, bf16>::value; };
 
 template <typename T> __device__ __forceinline__ typename Frag<T>::type load_chunk_guard(
     const T* p, int valid)  // valid = number of leading elements that are in range (<= 0: none)
@@ -75,19 +83,47 @@ template <typename T, bool TR> struct Stager {
             } else {
                 constexpr int CPR = 128 / Cfg::VEC;
                 int k = c / CPR, rc = (c % CPR) * Cfg::VEC;
+                if constexpr (UseTrRead<T, TR>::value) {
+                    *reinterpret_cast<F*>(lds + k * Cfg::TPITCH + rc) = r[i];     // untransposed; fragments come from tr reads
+                } else {
 #pragma unroll
-                for (int e = 0; e < Cfg::VEC; ++e) lds[(rc + e) * Cfg::PITCH + k] = r[i][e];
+                    for (int e = 0; e < Cfg::VEC; ++e) lds[(rc + e) * Cfg::PITCH + k] = r[i][e];
+                }
             }
         }
     }
+    // per-thread column sums of the staged chunks (TR only): chunk i covers columns rc..rc+VEC-1 of k-row k
+    __device__ __forceinline__ void add_colsum(float (&cs)[Cfg::VEC]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < Cfg::VEC; ++e) cs[e] += to_f32(r[i][e]);
+    }
 };
+
+// Operand fragment for output-row block starting at `row0` (32 rows) and k-step `ks` of the current tile.
+template <typename T, bool TR>
+__device__ __forceinline__ typename Frag<T>::type load_frag(const T* lds, int row0, int ks, int lane) {
+    typedef GemmCfg<T> Cfg;
+    typedef typename Frag<T>::type F;
+    if constexpr (UseTrRead<T, TR>::value) {
+        typedef __attribute__((address_space(3))) bf16x4 LdsV4;
+        const int q = (lane & 15) >> 2, col = row0 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4, k = ks + 8 * (lane >> 5) + q;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(lds + k * Cfg::TPITCH + col));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(lds + (k + 4) * Cfg::TPITCH + col));
+        const bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return f;
+    } else {
+        return *reinterpret_cast<const F*>(&lds[(row0 + (lane & 31)) * Cfg::PITCH + ks + (lane >> 5) * Cfg::VEC]);
+    }
+}
 
 template <typename T, typename TC, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     typedef GemmCfg<T> Cfg;
     typedef typename Frag<T>::type F;
-    __shared__ __attribute__((aligned(16))) T As[BM * Cfg::PITCH];
-    __shared__ __attribute__((aligned(16))) T Bs[BN * Cfg::PITCH];
+    __shared__ __attribute__((aligned(16))) T As[Cfg::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) T Bs[Cfg::LDS_ELEMS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -107,13 +143,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
     Stager<T, TA> sa;
     Stager<T, TB> sb;
+    float cs[Cfg::VEC];
+#pragma unroll
+    for (int e = 0; e < Cfg::VEC; ++e) cs[e] = 0.f;
+    const bool do_cs = TA && g.colsum_a != nullptr && blockIdx.x == 0;
     sa.load(A, g.lda, m0, g.M, kbeg, kend, tid);
     sb.load(B, g.ldb, n0, g.N, kbeg, kend, tid);
+    if (do_cs) sa.add_colsum(cs);
     sa.store(As, tid);
     sb.store(Bs, tid);
     __syncthreads();
 
-    const int frow = lane & 31, fk = (lane >> 5) * Cfg::VEC;
     for (int k0 = kbeg; k0 < kend; k0 += Cfg::BK) {
         const bool more = (k0 + Cfg::BK) < kend;
         if (more) {
@@ -124,11 +164,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int ks = 0; ks < Cfg::BK; ks += KStep<T>::value) {
             F a[2], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                a[i] = *reinterpret_cast<const F*>(&As[(wm * 64 + i * 32 + frow) * Cfg::PITCH + ks + fk]);
+            for (int i = 0; i < 2; ++i) a[i] = load_frag<T, TA>(As, wm * 64 + i * 32, ks, lane);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                b[j] = *reinterpret_cast<const F*>(&Bs[(wn * 64 + j * 32 + frow) * Cfg::PITCH + ks + fk]);
+            for (int j = 0; j < 2; ++j) b[j] = load_frag<T, TB>(Bs, wn * 64 + j * 32, ks, lane);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -136,12 +174,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
         __syncthreads();
         if (more) {
+            if (do_cs) sa.add_colsum(cs);   // here the prefetched registers are needed anyway (no extra wait)
             sa.store(As, tid);
             sb.store(Bs, tid);
             __syncthreads();
         }
     }
 
+    if (do_cs) {   // this thread's chunks always cover the same VEC output rows m0 + (tid % CPR) * VEC: combine the 256
+                   // per-thread partials in LDS (As is free after the last barrier), then ONE global atomic per row per block
+        constexpr int CPR = 128 / Cfg::VEC;
+        float* red = reinterpret_cast<float*>(As);
+        if (tid < 128) red[tid] = 0.f;
+        __syncthreads();
+        const int ml = (tid % CPR) * Cfg::VEC;
+#pragma unroll
+        for (int e = 0; e < Cfg::VEC; ++e) atomicAdd(&red[ml + e], cs[e]);
+        __syncthreads();
+        if (tid < 128 && m0 + tid < g.M) atomicAdd(&g.colsum_a[m0 + tid], red[tid]);
+    }
     TC* C = (TC*)g.C;
     const int col_l = lane & 31;
 #pragma unroll
@@ -184,7 +235,7 @@ template <typename T, typename TC> int launch(const GemmArgs& g, int ta, int tb,
 
 extern "C" int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, int N, int K, const void* A, long lda,
                         const void* B, long ldb, void* C, long ldc, const float* bias, int relu, int accumulate,
-                        int split_k, void* stream) {
+                        int split_k, float* colsum_a, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return OMR_ERR_ARG;
     const int vec = dtype == OMR_BF16 ? 8 : 4;
     if (lda % vec || ldb % vec) return OMR_ERR_ARG;                       // 16-byte aligned rows
@@ -193,7 +244,8 @@ extern "C" int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, i
     if (split_k > 1 && c_dtype != OMR_F32) return OMR_ERR_ARG;            // split-K accumulates with fp32 atomics
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.relu = relu; g.accum = accumulate; g.atomic = split_k > 1;
+    g.relu = relu; g.accum = accumulate; g.atomic = split_k > 1; g.colsum_a = colsum_a;
+    if (colsum_a && !transA) return OMR_ERR_ARG;
     const int bk = dtype == OMR_BF16 ? 32 : 16;
     int len = cdiv(cdiv(K, split_k), bk) * bk;
     g.ksplit_len = len;

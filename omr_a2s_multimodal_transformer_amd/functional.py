@@ -148,9 +148,7 @@ class LinearFn(Function):
         if relu and mask_own:
             g2 = K.relu_bwd(g2.contiguous(), y2)
         M = g2.shape[0]
-        if gb is not None:
-            K.colsum_into(g2, gb)
-        K.gemm(g2, x2, trans_a=True, trans_b=True, out=gw, accumulate=True, split_k=split_k_for(M))
+        K.gemm(g2, x2, trans_a=True, trans_b=True, out=gw, accumulate=True, split_k=split_k_for(M), colsum_a=gb)   # dW and db in one pass
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.gemm(g2, w, trans_b=True).view(xshape)

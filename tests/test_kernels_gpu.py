@@ -70,8 +70,10 @@ def test_gemm_tn_accumulate(dtype, split):
     dy, x = q(rnd((Mred, N), 6), dtype), q(rnd((Mred, K_), 7), dtype)
     init = rnd((N, K_), 8)
     out = init.to(dev()).clone()
-    K().gemm(dy.to(dev(), dtype), x.to(dev(), dtype), trans_a=True, trans_b=True, out=out, accumulate=True, split_k=split)
+    db = torch.ones(N, device=dev())
+    K().gemm(dy.to(dev(), dtype), x.to(dev(), dtype), trans_a=True, trans_b=True, out=out, accumulate=True, split_k=split, colsum_a=db)
     check(out, init + dy.t() @ x, dtype, scale=8, what="gemm TN")
+    check(db, 1.0 + dy.sum(0), dtype, scale=8, what="gemm TN fused column sums")
 
 
 def test_gemm_rejects_unaligned():
