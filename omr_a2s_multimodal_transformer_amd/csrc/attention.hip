@@ -11,10 +11,14 @@
 //   S^T = K . Q^T        (A = K tile from LDS, B = Q fragments held in registers)      -> softmax is lane-local
 //   O^T += V^T . P^T     (A = V^T tile from LDS, B = P^T straight from the accumulator registers, permuted-k order)
 // Backward: dQ kernel (same orientation) and dK/dV kernel (queries on the register axis, keys on the lanes).
+#include <type_traits>
+
 #include "omr_common.h"
 #include "omr_hip.h"
 
 namespace {
+
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 struct AttnArgs {
     const void* q; const void* k; const void* v; void* o;
@@ -47,6 +51,25 @@ template <> __device__ __forceinline__ bf16x8 load_kperm_frag<bf16>(const bf16* 
 }
 template <> __device__ __forceinline__ f32x4 load_kperm_frag<float>(const float* row, int kb, int s, int h) {
     return *reinterpret_cast<const f32x4*>(row + kb + 8 * s + 4 * h);
+}
+
+// The same permuted-k fragment, dtype dispatched:
+//   bf16: straight from the ROW-MAJOR tile [k][cols] with two ds_read_b64_tr_b16 (each returns 4 consecutive k rows of this
+//         lane's column) -- no transposed copy of the tile is ever staged;
+//   fp32: from a transposed tile [col][k] (staged with element-wise LDS stores; parity path only).
+template <typename T>
+__device__ __forceinline__ typename Frag<T>::type kperm_frag(const T* rowmajor, int prow, const T* transposed, int ptr_, int kb, int s,
+                                                              int col0, int lane) {
+    if constexpr (std::is_same<T, bf16>::value) {
+        typedef __attribute__((address_space(3))) bf16x4 LdsV4;
+        const int q = (lane & 15) >> 2, col = col0 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4, k = kb + 16 * s + 4 * (lane >> 5) + q;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(rowmajor + k * prow + col));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(rowmajor + (k + 8) * prow + col));
+        const bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return f;
+    } else {
+        return load_kperm_frag<T>(transposed + (col0 + (lane & 31)) * ptr_, kb, s, lane >> 5);
+    }
 }
 
 template <typename T> __device__ __forceinline__ typename Frag<T>::type acc_to_frag(const f32x16& acc, int s) {
@@ -107,8 +130,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     constexpr int PK = HD + VEC;          // Ks pitch
     constexpr int PV = BKV + 4;   // Vt pitch: 136 B (bf16) / 272 B (fp32) -> conflict-free permuted reads
     __shared__ __attribute__((aligned(16))) T Ks[BKV * PK];
-    __shared__ __attribute__((aligned(16))) T Vt[HD * PV];
-    __shared__ float bias_s[BKV];
+    constexpr bool TRD = std::is_same<T, bf16>::value;          // bf16: V is staged row-major and read with tr reads
+    __shared__ __attribute__((aligned(16))) T Vt[TRD ? 8 : HD * PV];
+    __shared__ __attribute__((aligned(16))) T Vs[TRD ? BKV * PK : 8];
+    __shared__ __attribute__((aligned(16))) float bias_s[BKV];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
@@ -130,6 +155,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    const float sc2 = a.scale * LOG2E;
+    const bool win_on = a.window > 0 && a.window < a.T;
 
     int kv_beg = 0, kv_end = a.S;
     if (a.causal) {
@@ -139,8 +166,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     for (int kv0 = kv_beg; kv0 < kv_end; kv0 += BKV) {
         __syncthreads();
         stage_rows<T, HD, BKV, PK>(Ks, K, a.ldk, kv0, a.S, tid);
-        stage_rows_t<T, HD, BKV, PV>(Vt, V, a.ldv, kv0, a.S, tid);
-        if (tid < BKV) bias_s[tid] = (a.key_bias && kv0 + tid < a.S) ? a.key_bias[(long)b * a.S + kv0 + tid] : 0.f;
+        if constexpr (TRD) stage_rows<T, HD, BKV, PK>(Vs, V, a.ldv, kv0, a.S, tid);
+        else stage_rows_t<T, HD, BKV, PV>(Vt, V, a.ldv, kv0, a.S, tid);
+        if (tid < BKV) bias_s[tid] = (a.key_bias && kv0 + tid < a.S) ? a.key_bias[(long)b * a.S + kv0 + tid] * LOG2E : 0.f;
         __syncthreads();
 
         f32x16 st[2];
@@ -154,32 +182,44 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 mma32(st[mb], kf, qf[ks]);
             }
         }
-        // scores -> masked, running max
+        // scores -> log2-domain logits (scale and bias pre-multiplied by log2 e), running max.  Tiles that are entirely
+        // visible for this wave's 32 query rows (the common case) skip every per-element mask test.
+        const int qw0 = q0 + wave * 32;
+        const bool full = (kv0 + BKV <= a.S) && (qw0 + 32 <= a.T) && lq < 0 &&
+                          (!a.causal || (kv0 + BKV - 1 <= qw0 && (!win_on || kv0 >= qw0 + 31 - a.window)));
         float mx = -INFINITY;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = mb * 32 + acc_row(r, lane);
-                const int key = kv0 + kl;
-                float s = st[mb][r] * a.scale + bias_s[kl];
-                if (!attn_visible(a, q, key, lq, lkv)) s = -INFINITY;
-                st[mb][r] = s;
-                mx = fmaxf(mx, s);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bz = *reinterpret_cast<const f32x4*>(&bias_s[mb * 32 + 8 * g + 4 * hh]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float sv = fmaf(st[mb][4 * g + e], sc2, bz[e]);
+                    if (!full && !attn_visible(a, q, kv0 + mb * 32 + 8 * g + 4 * hh + e, lq, lkv)) sv = -INFINITY;
+                    st[mb][4 * g + e] = sv;
+                    mx = fmaxf(mx, sv);
+                }
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_use);
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_use);
         float psum = 0.f;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __expf(st[mb][r] - m_use);   // exp(-inf) = 0 for masked keys
-                psum += p;
-                st[mb][r] = (a.drop_thresh == 0) ? p : p * attn_keep(a, b, h, q, kv0 + mb * 32 + acc_row(r, lane));
+                const float pv = __builtin_amdgcn_exp2f(st[mb][r] - m_use);   // exp2(-inf) = 0 for masked keys
+                psum += pv;
+                st[mb][r] = pv;
             }
+        if (a.drop_thresh != 0) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[mb][r] *= attn_keep(a, b, h, q, kv0 + mb * 32 + acc_row(r, lane));
+        }
         l_run = l_run * alpha + psum;
         m_run = m_new;
 #pragma unroll
@@ -194,7 +234,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 const F pf = acc_to_frag<T>(st[mb], s);
 #pragma unroll
                 for (int d = 0; d < NDB; ++d) {
-                    const F vf = load_kperm_frag<T>(&Vt[(d * 32 + (lane & 31)) * PV], mb * 32, s, hh);
+                    const F vf = kperm_frag<T>(Vs, PK, Vt, PV, mb * 32, s, d * 32, lane);
                     mma32(acc_o[d], vf, pf);
                 }
             }
@@ -207,7 +247,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[d * 32 + acc_row(r, lane)] = from_f32<T>(acc_o[d][r] * inv);
-        if (hh == 0 && a.lse) a.lse[((long)b * a.H + h) * a.T + q] = (l_tot > 0.f) ? m_run + logf(l_tot) : -INFINITY;
+        if (hh == 0 && a.lse) a.lse[((long)b * a.H + h) * a.T + q] = (l_tot > 0.f) ? (m_run + log2f(l_tot)) * LN2 : -INFINITY;
     }
 }
 
@@ -238,8 +278,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     constexpr int PV = BKV + 4;
     __shared__ __attribute__((aligned(16))) T Ks[BKV * PK];
     __shared__ __attribute__((aligned(16))) T Vs[BKV * PK];
-    __shared__ __attribute__((aligned(16))) T Kt[HD * PV];
-    __shared__ float bias_s[BKV];
+    constexpr bool TRD = std::is_same<T, bf16>::value;          // bf16: K^T fragments are tr reads of the row-major Ks tile
+    __shared__ __attribute__((aligned(16))) T Kt[TRD ? 8 : HD * PV];
+    __shared__ __attribute__((aligned(16))) float bias_s[BKV];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
@@ -256,8 +297,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         dof[ks] = q < a.T ? *reinterpret_cast<const F*>(DO + (long)q * a.lddo + ks * KS + hh * VEC) : frag_zero<T>();
     }
     const long sidx = ((long)b * a.H + h) * a.T + q;
-    const float lse = q < a.T ? a.lse[sidx] : 0.f;
+    const float lse2 = q < a.T ? a.lse[sidx] * LOG2E : 0.f;
     const float dl = q < a.T ? a.delta[sidx] : 0.f;
+    const float sc2 = a.scale * LOG2E;
+    const bool win_on = a.window > 0 && a.window < a.T, drop = a.drop_thresh != 0;
+    const int qw0 = q0 + wave * 32;
     int lq = -1, lkv = 0;
     if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
 
@@ -276,9 +320,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         __syncthreads();
         stage_rows<T, HD, BKV, PK>(Ks, K, a.ldk, kv0, a.S, tid);
         stage_rows<T, HD, BKV, PK>(Vs, V, a.ldv, kv0, a.S, tid);
-        stage_rows_t<T, HD, BKV, PV>(Kt, K, a.ldk, kv0, a.S, tid);
-        if (tid < BKV) bias_s[tid] = (a.key_bias && kv0 + tid < a.S) ? a.key_bias[(long)b * a.S + kv0 + tid] : 0.f;
+        if constexpr (!TRD) stage_rows_t<T, HD, BKV, PV>(Kt, K, a.ldk, kv0, a.S, tid);
+        if (tid < BKV) bias_s[tid] = (a.key_bias && kv0 + tid < a.S) ? a.key_bias[(long)b * a.S + kv0 + tid] * LOG2E : 0.f;
         __syncthreads();
+        const bool full = (kv0 + BKV <= a.S) && (qw0 + 32 <= a.T) && lq < 0 &&
+                          (!a.causal || (kv0 + BKV - 1 <= qw0 && (!win_on || kv0 >= qw0 + 31 - a.window)));
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             f32x16 st, dp;
@@ -292,20 +338,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 mma32(dp, vf, dof[ks]);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = mb * 32 + acc_row(r, lane);
-                const int key = kv0 + kl;
-                float p = 0.f;
-                if (attn_visible(a, q, key, lq, lkv)) p = __expf(st[r] * a.scale + bias_s[kl] - lse);
-                const float keep = attn_keep(a, b, h, q, key);
-                st[r] = p * (dp[r] * keep - dl);     // dS^T
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bz = *reinterpret_cast<const f32x4*>(&bias_s[mb * 32 + 8 * g + 4 * hh]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    float pv = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, bz[e]) - lse2);
+                    if (!full && !attn_visible(a, q, kv0 + mb * 32 + 8 * g + 4 * hh + e, lq, lkv)) pv = 0.f;
+                    float dpv = dp[r];
+                    if (drop) dpv *= attn_keep(a, b, h, q, kv0 + mb * 32 + 8 * g + 4 * hh + e);
+                    st[r] = pv * (dpv - dl);     // dS^T
+                }
             }
 #pragma unroll
             for (int s = 0; s < NFR; ++s) {
                 const F sf = acc_to_frag<T>(st, s);
 #pragma unroll
                 for (int d = 0; d < NDB; ++d) {
-                    const F kf = load_kperm_frag<T>(&Kt[(d * 32 + (lane & 31)) * PV], mb * 32, s, hh);
+                    const F kf = kperm_frag<T>(Ks, PK, Kt, PV, mb * 32, s, d * 32, lane);
                     mma32(acc_q[d], kf, sf);
                 }
             }
@@ -333,8 +383,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     constexpr int PT = BQ + 4;   // transposed tiles [d][q]
     __shared__ __attribute__((aligned(16))) T Qs[BQ * PK];
     __shared__ __attribute__((aligned(16))) T Ds[BQ * PK];
-    __shared__ __attribute__((aligned(16))) T Qt[HD * PT];
-    __shared__ __attribute__((aligned(16))) T Dt[HD * PT];
+    constexpr bool TRD = std::is_same<T, bf16>::value;          // bf16: Q^T / dO^T fragments are tr reads of Qs / Ds
+    __shared__ __attribute__((aligned(16))) T Qt[TRD ? 8 : HD * PT];
+    __shared__ __attribute__((aligned(16))) T Dt[TRD ? 8 : HD * PT];
     __shared__ __attribute__((aligned(16))) float lse_s[BQ];
     __shared__ __attribute__((aligned(16))) float del_s[BQ];
 
@@ -352,7 +403,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         kf[ks] = key < a.S ? *reinterpret_cast<const F*>(K + (long)key * a.ldk + ks * KS + hh * VEC) : frag_zero<T>();
         vf[ks] = key < a.S ? *reinterpret_cast<const F*>(V + (long)key * a.ldv + ks * KS + hh * VEC) : frag_zero<T>();
     }
-    const float kb = (a.key_bias && key < a.S) ? a.key_bias[(long)b * a.S + key] : 0.f;
+    const float kb2 = (a.key_bias && key < a.S) ? a.key_bias[(long)b * a.S + key] * LOG2E : 0.f;
+    const float sc2 = a.scale * LOG2E;
+    const bool win_on = a.window > 0 && a.window < a.T, drop = a.drop_thresh != 0;
+    const int kw0 = k0 + wave * 32;
     int lq = -1, lkv = 0;
     if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
 
@@ -372,10 +426,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         __syncthreads();
         stage_rows<T, HD, BQ, PK>(Qs, Q, a.ldq, q0, a.T, tid);
         stage_rows<T, HD, BQ, PK>(Ds, DO, a.lddo, q0, a.T, tid);
-        stage_rows_t<T, HD, BQ, PT>(Qt, Q, a.ldq, q0, a.T, tid);
-        stage_rows_t<T, HD, BQ, PT>(Dt, DO, a.lddo, q0, a.T, tid);
+        if constexpr (!TRD) {
+            stage_rows_t<T, HD, BQ, PT>(Qt, Q, a.ldq, q0, a.T, tid);
+            stage_rows_t<T, HD, BQ, PT>(Dt, DO, a.lddo, q0, a.T, tid);
+        }
         if (tid < BQ) {
-            lse_s[tid] = q0 + tid < a.T ? a.lse[sbase + q0 + tid] : 0.f;
+            lse_s[tid] = q0 + tid < a.T ? a.lse[sbase + q0 + tid] * LOG2E : 0.f;
             del_s[tid] = q0 + tid < a.T ? a.delta[sbase + q0 + tid] : 0.f;
         }
         __syncthreads();
@@ -390,15 +446,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
             mma32(dp, df, vf[ks]);
         }
         f32x16 pd;  // dropped probabilities (for dV)
+        const bool full = (kw0 + 32 <= a.S) && (q0 + BQ <= a.T) && lq < 0 &&
+                          (!a.causal || (kw0 + 31 <= q0 && (!win_on || kw0 >= q0 + BQ - 1 - a.window)));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ql = acc_row(r, lane);
-            const int qq = q0 + ql;
-            float p = 0.f;
-            if (attn_visible(a, qq, key, lq, lkv)) p = __expf(st[r] * a.scale + kb - lse_s[ql]);
-            const float keep = attn_keep(a, b, h, qq, key);
-            pd[r] = p * keep;
-            st[r] = p * (dp[r] * keep - del_s[ql]);    // dS
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lse_s[8 * g + 4 * hh]);   // already * log2 e
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(&del_s[8 * g + 4 * hh]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e, qq = q0 + 8 * g + 4 * hh + e;
+                float pv = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, kb2) - l4[e]);
+                if (!full && !attn_visible(a, qq, key, lq, lkv)) pv = 0.f;
+                float keep = 1.f;
+                if (drop) keep = attn_keep(a, b, h, qq, key);
+                pd[r] = pv * keep;
+                st[r] = pv * (dp[r] * keep - d4[e]);    // dS
+            }
         }
 #pragma unroll
         for (int s = 0; s < NFR; ++s) {
@@ -406,9 +469,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
             const F sf = acc_to_frag<T>(st, s);
 #pragma unroll
             for (int d = 0; d < NDB; ++d) {
-                const F dtf = load_kperm_frag<T>(&Dt[(d * 32 + (lane & 31)) * PT], 0, s, hh);
+                const F dtf = kperm_frag<T>(Ds, PK, Dt, PT, 0, s, d * 32, lane);
                 mma32(acc_v[d], pf, dtf);
-                const F qtf = load_kperm_frag<T>(&Qt[(d * 32 + (lane & 31)) * PT], 0, s, hh);
+                const F qtf = kperm_frag<T>(Qs, PK, Qt, PT, 0, s, d * 32, lane);
                 mma32(acc_k[d], sf, qtf);
             }
         }

@@ -719,7 +719,7 @@ extern "C" int omr_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, flo
     const int vec = dtype == OMR_BF16 ? 8 : 4;
     if (C % vec || 256 % (C / vec)) return OMR_ERR_UNSUPPORTED;
     long total = (long)B * H * W;
-    int ppb = 128;
+    int ppb = 512;
     int grid = (int)((total + ppb - 1) / ppb);
     size_t shm = (size_t)C * 10 * sizeof(float);
     DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<T>), grid, 256, shm, (hipStream_t)stream, (const T*)x, (const T*)dy, dw, db,
