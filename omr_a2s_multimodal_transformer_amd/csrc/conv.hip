@@ -435,36 +435,36 @@ template <typename T, int TH> int launch_wgrad(const WgradArgs& a, hipStream_t s
 // ------------------------------------------------------------------------------------------------
 // First layer: Cin = 1 -> COUT (<= 32) with ReLU.  One thread per output pixel; K = 9, HBM-bound.
 template <typename T, int COUT>
-__global__ void conv1_direct_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, int B,
-                                    int H, int Wd, int relu) {
+__global__ __launch_bounds__(256) void conv1_direct_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, int B,
+                                                           int H, int Wd, int relu) {
     __shared__ float ws[COUT * 9 + COUT];
     for (int i = threadIdx.x; i < COUT * 9; i += blockDim.x) ws[i] = to_f32(w[i]);
     for (int i = threadIdx.x; i < COUT; i += blockDim.x) ws[COUT * 9 + i] = bias ? bias[i] : 0.f;
     __syncthreads();
-    const long total = (long)B * H * Wd;
-    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(p % Wd); const long q = p / Wd; const int i = (int)(q % H); const long b = q / H;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;      // image column; blockIdx.y walks image rows (32-bit math only)
+    if (j >= Wd) return;
+    const int rows = B * H;
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int i = row % H;
         float in[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int ii = i + t / 3 - 1, jj = j + t % 3 - 1;
-            in[t] = (ii >= 0 && ii < H && jj >= 0 && jj < Wd) ? to_f32(x[(b * H + ii) * Wd + jj]) : 0.f;
-        }
-        T out[COUT];
-#pragma unroll
-        for (int n = 0; n < COUT; ++n) {
-            float s = ws[COUT * 9 + n];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) s += ws[n * 9 + t] * in[t];
-            out[n] = from_f32<T>(relu ? fmaxf(s, 0.f) : s);
+            in[t] = (ii >= 0 && ii < H && jj >= 0 && jj < Wd) ? to_f32(x[(long)(row + t / 3 - 1) * Wd + jj]) : 0.f;
         }
         typedef typename Frag<T>::type F;
-        F* dst = reinterpret_cast<F*>(y + p * COUT);
+        F* dst = reinterpret_cast<F*>(y + ((long)row * Wd + j) * COUT);
 #pragma unroll
         for (int v = 0; v < COUT / Frag<T>::N; ++v) {
             F f;
 #pragma unroll
-            for (int e = 0; e < Frag<T>::N; ++e) f[e] = out[v * Frag<T>::N + e];
+            for (int e = 0; e < Frag<T>::N; ++e) {
+                const int n = v * Frag<T>::N + e;
+                float s = ws[COUT * 9 + n];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) s += ws[n * 9 + t] * in[t];
+                f[e] = from_f32<T>(relu ? fmaxf(s, 0.f) : s);
+            }
             dst[v] = f;
         }
     }
@@ -576,57 +576,90 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x,
     }
 }
 
-// dW[c][tap] += sum_p dY[p][c] xin[p+tap][c];  db[c] += sum_p dY[p][c].  Thread = (8/4-channel group, pixel phase) with
-// 16-byte loads; per-thread register partials -> LDS fp32 -> one global fp32 atomic per (c, tap) per block.
-template <typename T>
-__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw,
-                                                              float* __restrict__ db, const float* __restrict__ mean,
-                                                              const float* __restrict__ rstd, int B, int H, int Wd, int C, int pix_per_block) {
+// dW[c][tap] += sum_p dY[p][c] xin[p+tap][c];  db[c] += sum_p dY[p][c].
+// Thread = (image column j, channel group): it walks DOWN the rows of one image with a 3x3 register window of the
+// (normalised) input, so each pixel costs 3 new 16-byte x loads + 1 dY load for 9*VEC FMAs.  The 10*VEC partial sums stay
+// in registers for the whole image column; wave shuffles fold the columns, then LDS and one global atomic per block.
+template <int R, typename T, typename LoadX>
+__device__ __forceinline__ void dw_wgrad_step(int r, int H, const T* __restrict__ dyp, long dy_row_stride, float (&xw)[3][3][Frag<T>::N],
+                                              float (&acc)[10][Frag<T>::N], LoadX loadx) {
     typedef typename Frag<T>::type F;
     constexpr int VEC = Frag<T>::N;
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [C][10]
+    if (r >= H) return;
+    const F gv = *reinterpret_cast<const F*>(dyp + (long)r * dy_row_stride);
+    float g[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { g[e] = to_f32(gv[e]); acc[9][e] += g[e]; }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[kh * 3 + kw][e] += g[e] * xw[(R + kh) % 3][kw][e];
+    loadx(r + 2, xw[R % 3]);      // slot R held row r-1: refill it with row r+2
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd, int B, int H, int Wd, int C) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [C][10]
     for (int i = threadIdx.x; i < C * 10; i += blockDim.x) red[i] = 0.f;
     __syncthreads();
-    const int ncg = C / VEC;
-    const int cg = threadIdx.x % ncg, phase = threadIdx.x / ncg, nphase = blockDim.x / ncg;
-    const long total = (long)B * H * Wd;
-    const long p0 = (long)blockIdx.x * pix_per_block;
-    const long p1 = p0 + pix_per_block < total ? p0 + pix_per_block : total;
+    const int ncg = C / VEC, cpb = blockDim.x / ncg;
+    const int cg = threadIdx.x % ncg, j = blockIdx.x * cpb + threadIdx.x / ncg, b = blockIdx.y;
     float acc[10][VEC];
 #pragma unroll
     for (int t = 0; t < 10; ++t)
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
-    if (phase < nphase) {
-        for (long p = p0 + phase; p < p1; p += nphase) {
-            const int j = (int)(p % Wd); const long q = p / Wd; const int ii = (int)(q % H); const long b = q / H;
-            const F gv = *reinterpret_cast<const F*>(dy + p * C + cg * VEC);
-            float g[VEC], mu[VEC], rs[VEC];
+    if (j < Wd) {
+        float mu[VEC], rs[VEC];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                g[e] = to_f32(gv[e]);
-                acc[9][e] += g[e];
-                mu[e] = mean ? mean[b * C + cg * VEC + e] : 0.f;
-                rs[e] = rstd ? rstd[b * C + cg * VEC + e] : 1.f;
-            }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int yy = ii + t / 3 - 1, xx = j + t % 3 - 1;
-                if (yy < 0 || yy >= H || xx < 0 || xx >= Wd) continue;
-                const F xv = *reinterpret_cast<const F*>(x + ((b * H + yy) * Wd + xx) * C + cg * VEC);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[t][e] += g[e] * ((to_f32(xv[e]) - mu[e]) * rs[e]);
-            }
+        for (int e = 0; e < VEC; ++e) {
+            mu[e] = mean ? mean[(long)b * C + cg * VEC + e] : 0.f;
+            rs[e] = rstd ? rstd[(long)b * C + cg * VEC + e] : 1.f;
         }
+        const T* xb = x + (long)b * H * Wd * C + cg * VEC;
+        auto loadx = [&](int r, float (&row)[3][VEC]) {
 #pragma unroll
-        for (int t = 0; t < 10; ++t)
+            for (int kw = 0; kw < 3; ++kw) {
+                const int jj = j + kw - 1;
+                if (r >= 0 && r < H && jj >= 0 && jj < Wd) {
+                    const F v = *reinterpret_cast<const F*>(xb + ((long)r * Wd + jj) * C);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) atomicAdd(&red[(cg * VEC + e) * 10 + t], acc[t][e]);
+                    for (int e = 0; e < VEC; ++e) row[kw][e] = (to_f32(v[e]) - mu[e]) * rs[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) row[kw][e] = 0.f;   // zero padding lives in the normalised space
+                }
+            }
+        };
+        float xw[3][3][VEC];
+        loadx(-1, xw[0]); loadx(0, xw[1]); loadx(1, xw[2]);
+        const T* dyp = dy + ((long)b * H * Wd + j) * C + cg * VEC;
+        const long rs_ = (long)Wd * C;
+        for (int r = 0; r < H; r += 3) {
+            dw_wgrad_step<0, T>(r, H, dyp, rs_, xw, acc, loadx);
+            dw_wgrad_step<1, T>(r + 1, H, dyp, rs_, xw, acc, loadx);
+            dw_wgrad_step<2, T>(r + 2, H, dyp, rs_, xw, acc, loadx);
+        }
     }
+    // fold the columns that share this lane's channel group (lanes cg, cg+ncg, ...), then LDS, then global
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float v = acc[t][e];
+            for (int o = ncg; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+            if (lane < ncg) atomicAdd(&red[(cg * VEC + e) * 10 + t], v);
+        }
     __syncthreads();
     for (int i = threadIdx.x; i < C * 10; i += blockDim.x) {
-        const int c = i / 10, t = i % 10;
-        if (t < 9) atomicAdd(&dw[c * 9 + t], red[i]);
+        const int c = i / 10, tt = i % 10;
+        if (tt < 9) atomicAdd(&dw[c * 9 + tt], red[i]);
         else if (db) atomicAdd(&db[c], red[i]);
     }
 }
@@ -649,10 +682,11 @@ extern "C" int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const fl
     hipStream_t s = (hipStream_t)stream;
     if (CIN == 1) {
         if (dil_h != 1 || dil_w != 1 || stride_h != 1 || stride_w != 1 || in_mean || out_mask || Ho != H || Wo != W) return OMR_ERR_UNSUPPORTED;
-        long total = (long)B * H * W;
+        int gy1 = B * H; if (gy1 > 1024) gy1 = 1024;
+        dim3 g1(cdiv(W, 256), gy1);
         DISPATCH_T(dtype, {
-            if (COUT == 16) hipLaunchKernelGGL((conv1_direct_kernel<T, 16>), ew_grid(total), 256, 0, s, (const T*)x, (const T*)w, bias, (T*)y, B, H, W, relu);
-            else if (COUT == 32) hipLaunchKernelGGL((conv1_direct_kernel<T, 32>), ew_grid(total), 256, 0, s, (const T*)x, (const T*)w, bias, (T*)y, B, H, W, relu);
+            if (COUT == 16) hipLaunchKernelGGL((conv1_direct_kernel<T, 16>), g1, 256, 0, s, (const T*)x, (const T*)w, bias, (T*)y, B, H, W, relu);
+            else if (COUT == 32) hipLaunchKernelGGL((conv1_direct_kernel<T, 32>), g1, 256, 0, s, (const T*)x, (const T*)w, bias, (T*)y, B, H, W, relu);
             else return OMR_ERR_UNSUPPORTED;
         });
         OMR_CHECK_LAUNCH();
@@ -719,11 +753,11 @@ extern "C" int omr_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, flo
     const int vec = dtype == OMR_BF16 ? 8 : 4;
     if (C % vec || 256 % (C / vec)) return OMR_ERR_UNSUPPORTED;
     long total = (long)B * H * W;
-    int ppb = 512;
-    int grid = (int)((total + ppb - 1) / ppb);
-    size_t shm = (size_t)C * 10 * sizeof(float);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<T>), grid, 256, shm, (hipStream_t)stream, (const T*)x, (const T*)dy, dw, db,
-                                         in_mean, in_rstd, B, H, W, C, ppb));
+    const int ncg = C / vec;
+    if (ncg > 64 || 64 % ncg) return OMR_ERR_UNSUPPORTED;          // a wave holds whole channel-group sets
+    dim3 grid(cdiv(W, 256 / ncg), B);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<T>), grid, 256, (size_t)C * 10 * sizeof(float), (hipStream_t)stream,
+                                         (const T*)x, (const T*)dy, dw, db, in_mean, in_rstd, B, H, W, C));
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }

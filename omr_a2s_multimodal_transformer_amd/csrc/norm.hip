@@ -113,87 +113,95 @@ __global__ __launch_bounds__(256) void instnorm_bwd_apply_kernel(const T* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// out = LayerNorm(x + res) * gamma + beta ; one wave per row, d <= 1024, d % 64 == 0 not required.
-// Saves mean and rstd (fp32) for the backward.
-template <typename T, int MAXPER>
+// out = LayerNorm(x + res) * gamma + beta.  One wave per row; lane l owns the PER = d/64 CONSECUTIVE elements
+// [l*PER, (l+1)*PER) so every tensor is touched with one vector load/store per lane per row.  Saves mean and rstd.
+template <typename T, int PER>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ out, float* __restrict__ mean,
-                                                         float* __restrict__ rstd, long M, int d, float eps) {
+                                                         float* __restrict__ rstd, long M, float eps) {
+    typedef __attribute__((ext_vector_type(PER))) T VT;
+    typedef __attribute__((ext_vector_type(PER))) float VF;
+    constexpr int d = PER * 64;
     const int lane = threadIdx.x & 63;
     const long row = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
-    float v[MAXPER];
+    const VT xv = *reinterpret_cast<const VT*>(x + row * d + lane * PER);
+    const VF gm = *reinterpret_cast<const VF*>(gamma + lane * PER), bt = *reinterpret_cast<const VF*>(beta + lane * PER);
+    float v[PER];
     float s = 0.f;
+    if (res) {
+        const VT rv = *reinterpret_cast<const VT*>(res + row * d + lane * PER);
 #pragma unroll
-    for (int i = 0; i < MAXPER; ++i) {
-        int c = lane + i * 64;
-        v[i] = c < d ? to_f32(x[row * d + c]) + (res ? to_f32(res[row * d + c]) : 0.f) : 0.f;
-        s += v[i];
+        for (int i = 0; i < PER; ++i) v[i] = to_f32(xv[i]) + to_f32(rv[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) v[i] = to_f32(xv[i]);
     }
-    const float mu = wave_sum(s) / d;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s += v[i];
+    const float mu = wave_sum(s) * (1.f / d);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXPER; ++i) {
-        int c = lane + i * 64;
-        float t = c < d ? v[i] - mu : 0.f;
-        q += t * t;
-    }
-    const float rs = rsqrtf(wave_sum(q) / d + eps);
+    for (int i = 0; i < PER; ++i) { const float t = v[i] - mu; q += t * t; }
+    const float rs = rsqrtf(wave_sum(q) * (1.f / d) + eps);
+    VT o;
 #pragma unroll
-    for (int i = 0; i < MAXPER; ++i) {
-        int c = lane + i * 64;
-        if (c < d) out[row * d + c] = from_f32<T>((v[i] - mu) * rs * gamma[c] + beta[c]);
-    }
+    for (int i = 0; i < PER; ++i) o[i] = from_f32<T>((v[i] - mu) * rs * gm[i] + bt[i]);
+    *reinterpret_cast<VT*>(out + row * d + lane * PER) = o;
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
 // Backward: s = x + res, xhat = (s - mean) * rstd, gh = dy * gamma
 //   ds = rstd * (gh - mean_d(gh) - xhat * mean_d(gh * xhat))      (gradient of BOTH x and res)
-//   dgamma[c] += sum_rows dy * xhat ; dbeta[c] += sum_rows dy     (fp32 atomics, one add per block per column)
-template <typename T, int MAXPER>
+//   dgamma[c] += sum_rows dy * xhat ; dbeta[c] += sum_rows dy     (register partials per wave -> LDS -> one atomic per column per block)
+template <typename T, int PER>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ res,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, T* __restrict__ ds, float* __restrict__ dgamma,
-                                                         float* __restrict__ dbeta, long M, int d, int rows_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float dyn[];  // [2][d] per-block column partials
-    float* cg = dyn;
-    float* cb = dyn + d;
-    for (int i = threadIdx.x; i < 2 * d; i += blockDim.x) dyn[i] = 0.f;
+                                                         float* __restrict__ dbeta, long M, int rows_per_block) {
+    typedef __attribute__((ext_vector_type(PER))) T VT;
+    typedef __attribute__((ext_vector_type(PER))) float VF;
+    constexpr int d = PER * 64;
+    __shared__ float cg[d], cb[d];
+    for (int i = threadIdx.x; i < d; i += blockDim.x) { cg[i] = 0.f; cb[i] = 0.f; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const long r0 = (long)blockIdx.x * rows_per_block;
-    float ag[MAXPER], ab[MAXPER];
+    const VF gm = *reinterpret_cast<const VF*>(gamma + lane * PER);
+    float ag[PER], ab[PER];
 #pragma unroll
-    for (int i = 0; i < MAXPER; ++i) ag[i] = ab[i] = 0.f;
+    for (int i = 0; i < PER; ++i) ag[i] = ab[i] = 0.f;
     for (long row = r0 + wv; row < r0 + rows_per_block && row < M; row += nw) {
         const float mu = mean[row], rs = rstd[row];
-        float xh[MAXPER], gh[MAXPER];
-        float s1 = 0.f, s2 = 0.f;
+        const VT xv = *reinterpret_cast<const VT*>(x + row * d + lane * PER);
+        const VT gv = *reinterpret_cast<const VT*>(dy + row * d + lane * PER);
+        float sv[PER];
+        if (res) {
+            const VT rv = *reinterpret_cast<const VT*>(res + row * d + lane * PER);
 #pragma unroll
-        for (int i = 0; i < MAXPER; ++i) {
-            int c = lane + i * 64;
-            if (c < d) {
-                float sv = to_f32(x[row * d + c]) + (res ? to_f32(res[row * d + c]) : 0.f);
-                float g = to_f32(dy[row * d + c]);
-                xh[i] = (sv - mu) * rs;
-                gh[i] = g * gamma[c];
-                ag[i] += g * xh[i];
-                ab[i] += g;
-                s1 += gh[i]; s2 += gh[i] * xh[i];
-            } else { xh[i] = gh[i] = 0.f; }
-        }
-        s1 = wave_sum(s1) / d; s2 = wave_sum(s2) / d;
+            for (int i = 0; i < PER; ++i) sv[i] = to_f32(xv[i]) + to_f32(rv[i]);
+        } else {
 #pragma unroll
-        for (int i = 0; i < MAXPER; ++i) {
-            int c = lane + i * 64;
-            if (c < d) ds[row * d + c] = from_f32<T>(rs * (gh[i] - s1 - xh[i] * s2));
+            for (int i = 0; i < PER; ++i) sv[i] = to_f32(xv[i]);
         }
+        float xh[PER], gh[PER], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const float g = to_f32(gv[i]);
+            xh[i] = (sv[i] - mu) * rs;
+            gh[i] = g * gm[i];
+            ag[i] += g * xh[i];
+            ab[i] += g;
+            s1 += gh[i]; s2 += gh[i] * xh[i];
+        }
+        s1 = wave_sum(s1) * (1.f / d); s2 = wave_sum(s2) * (1.f / d);
+        VT o;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) o[i] = from_f32<T>(rs * (gh[i] - s1 - xh[i] * s2));
+        *reinterpret_cast<VT*>(ds + row * d + lane * PER) = o;
     }
 #pragma unroll
-    for (int i = 0; i < MAXPER; ++i) {
-        int c = lane + i * 64;
-        if (c < d) { atomicAdd(&cg[c], ag[i]); atomicAdd(&cb[c], ab[i]); }
-    }
+    for (int i = 0; i < PER; ++i) { atomicAdd(&cg[lane * PER + i], ag[i]); atomicAdd(&cb[lane * PER + i], ab[i]); }
     __syncthreads();
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
         atomicAdd(&dgamma[c], cg[c]);
@@ -247,30 +255,31 @@ extern "C" int omr_instnorm_bwd(int dtype, const void* dxhat, const void* x, con
     return OMR_OK;
 }
 
+#define LN_DISPATCH_PER(KERNEL, ...)                                                                       \
+    switch (d / 64) {                                                                                      \
+        case 2: hipLaunchKernelGGL((KERNEL<T, 2>), __VA_ARGS__); break;                                    \
+        case 4: hipLaunchKernelGGL((KERNEL<T, 4>), __VA_ARGS__); break;                                    \
+        case 8: hipLaunchKernelGGL((KERNEL<T, 8>), __VA_ARGS__); break;                                    \
+        default: return OMR_ERR_UNSUPPORTED;                                                               \
+    }
+
 extern "C" int omr_add_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* out, float* mean,
                                      float* rstd, long M, int d, float eps, void* stream) {
-    if (M <= 0 || d <= 0 || d > 1024) return OMR_ERR_ARG;
+    if (M <= 0 || d <= 0 || d % 64) return OMR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     int grid = cdiv(M, 4);
-    DISPATCH_T(dtype, {
-        if (d <= 256) hipLaunchKernelGGL((add_ln_fwd_kernel<T, 4>), grid, 256, 0, s, (const T*)x, (const T*)res, gamma, beta, (T*)out, mean, rstd, M, d, eps);
-        else hipLaunchKernelGGL((add_ln_fwd_kernel<T, 16>), grid, 256, 0, s, (const T*)x, (const T*)res, gamma, beta, (T*)out, mean, rstd, M, d, eps);
-    });
+    DISPATCH_T(dtype, { LN_DISPATCH_PER(add_ln_fwd_kernel, grid, 256, 0, s, (const T*)x, (const T*)res, gamma, beta, (T*)out, mean, rstd, M, eps) });
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }
 
 extern "C" int omr_add_layernorm_bwd(int dtype, const void* dy, const void* x, const void* res, const float* gamma, const float* mean,
                                      const float* rstd, void* ds, float* dgamma, float* dbeta, long M, int d, void* stream) {
-    if (M <= 0 || d <= 0 || d > 1024) return OMR_ERR_ARG;
+    if (M <= 0 || d <= 0 || d % 64) return OMR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    int rpb = 64;
+    int rpb = 32;
     int grid = cdiv(M, rpb);
-    size_t shm = 2 * (size_t)d * sizeof(float);
-    DISPATCH_T(dtype, {
-        if (d <= 256) hipLaunchKernelGGL((add_ln_bwd_kernel<T, 4>), grid, 256, shm, s, (const T*)dy, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)ds, dgamma, dbeta, M, d, rpb);
-        else hipLaunchKernelGGL((add_ln_bwd_kernel<T, 16>), grid, 256, shm, s, (const T*)dy, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)ds, dgamma, dbeta, M, d, rpb);
-    });
+    DISPATCH_T(dtype, { LN_DISPATCH_PER(add_ln_bwd_kernel, grid, 256, 0, s, (const T*)dy, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)ds, dgamma, dbeta, M, rpb) });
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }
