@@ -110,7 +110,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     S = ((H + 15) // 16) * ((W + 7) // 8)
     step_flops = 3.0 * fwd_flops_per_sample(H, W, T, S, 256, args.layers, V)
@@ -170,16 +170,30 @@ def roofline_dominant_kernel(B, H, W, dtype):
             "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1), "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)}
 
 
-def cpu_baseline(H, W, T, V, layers):
-    """The CPU oracle (oracle/ref_cpu.py, fp32, plain torch ops = the reference's arithmetic) timed on this node's host
-    cores: forward + backward + Adam on a bounded sample (B=2 at the benchmark shapes, 1 warm-up + 1 timed step)."""
-    from oracle import ref_cpu as R
-    from omr_a2s_multimodal_transformer_amd import synthetic as syn
-    cores = os.cpu_count() or 1
+def usable_cores():
+    """Host cores this process may really use: scheduler affinity capped by the cgroup CPU quota (the GPU box shows
+    256 logical CPUs but grants 16: running torch with 256 threads there is a 20x slowdown, not a baseline)."""
+    n = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(H, W, T, V, layers):
+    """The CPU oracle (oracle/ref_cpu.py, fp32, plain torch ops = the reference's arithmetic) timed on this node's host
+    cores: forward + backward + Adam on a bounded sample (B=2 at the benchmark shapes; one timed step after a small
+    thread-pool warm-up)."""
+    from oracle import ref_cpu as R
+    from omr_a2s_multimodal_transformer_amd import synthetic as syn
+    cores = usable_cores()
     torch.set_num_threads(cores)
     Bc = 2
     sd = syn.seeded_state_dict(syn.transformer_shapes(V, 256, 256, layers), 0, mode="torch_default")
@@ -188,23 +202,26 @@ def cpu_baseline(H, W, T, V, layers):
     ps = list(sd.values())
     m = [torch.zeros_like(p) for p in ps]
     v2 = [torch.zeros_like(p) for p in ps]
-    x, xl, y_in, y_out = syn.synthetic_unimodal_batch(Bc, H, W, T, V, syn.GRANDSTAFF_SOS, syn.GRANDSTAFF_EOS, seed=1)
     cfg = R.OracleCfg(num_layers=layers)
 
-    def one(step):
+    def one(step, x, xl, y_in, y_out, h, w):
         for p in ps:
             p.grad = None
-        loss = R.ce_loss(R.transformer_forward(sd, x, xl, y_in, cfg, H, W), y_out)
+        loss = R.ce_loss(R.transformer_forward(sd, x, xl, y_in, cfg, h, w), y_out)
         loss.backward()
         with torch.no_grad():
             R.adam_step(ps, [p.grad for p in ps], m, v2, step)
 
-    one(1)
+    print(f"[bench] cpu_baseline: warm-up on {cores} threads", file=sys.stderr, flush=True)
+    one(1, *syn.synthetic_unimodal_batch(1, 32, 128, 16, V, syn.GRANDSTAFF_SOS, syn.GRANDSTAFF_EOS, seed=2), 32, 128)
+    batch = syn.synthetic_unimodal_batch(Bc, H, W, T, V, syn.GRANDSTAFF_SOS, syn.GRANDSTAFF_EOS, seed=1)
+    print("[bench] cpu_baseline: timed step", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
-    one(2)
+    one(2, *batch, H, W)
     dt = time.perf_counter() - t0
+    print(f"[bench] cpu_baseline: {dt:.1f} s", file=sys.stderr, flush=True)
     return {"value": round(Bc / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"1 timed step (after 1 warm-up) of B={Bc} at the benchmark shapes ({H}x{W}, T={T}, L={layers}, V={V}), fp32, dropout off"}
+            "sample": f"1 timed step of B={Bc} at the benchmark shapes ({H}x{W}, T={T}, L={layers}, V={V}), fp32, dropout off"}
 
 
 if __name__ == "__main__":
