@@ -53,169 +53,215 @@ struct ConvArgs {
 };
 
 // ------------------------------------------------------------------------------------------------
-// 3x3 conv as implicit GEMM.  Block = 256 threads = 4 waves; output tile = (4*RPW) rows x 32 cols x NT
-// couts.  Wave w owns tile rows [w*RPW, (w+1)*RPW) (one M-block each) and all NT/32 N-blocks.
-template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW>
+// 3x3 conv as implicit GEMM.  Block = 256 threads = 4 waves; output tile = (4*RPW) rows x 32 cols x NT couts.
+// Wave w owns tile rows [w*RPW, (w+1)*RPW) and all NT/32 cout blocks.  Blocks are PERSISTENT over output tiles
+// (grid-stride): when the whole reduction fits one channel chunk (CIN == CK: every 16/32-channel layer, i.e. all the
+// full-resolution ones) the weight tile is staged into LDS once per block instead of once per tile.
+// MFMA orientation: D[cout][pixel] (weights = A operand) so each lane owns one output pixel and its 16 accumulator
+// registers are 4 runs of 4 consecutive couts: bias/ReLU in registers, one 8-byte LDS store per run, then the tile
+// leaves LDS as 16-byte row-contiguous global stores (direct 8-byte global stores were measured 15 % slower).
+template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, bool SINGLE>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
     typedef typename Frag<T>::type F;
+    typedef __attribute__((ext_vector_type(4))) T T4;
     constexpr int VEC = Frag<T>::N;
     constexpr int CKP = CK + VEC;           // pitch (elements): 16-byte odd multiple -> conflict-free b128 reads
     constexpr int NB = NT / 32;
     constexpr int TH = 4 * RPW;
+    constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3, NPIX = IH * IW;
+    constexpr int CPP = CK / VEC;           // 16-byte chunks per pixel per channel chunk
+    constexpr int OP = NT + VEC;            // output staging pitch (elements)
+    // LDS: [Xs | Ws].  The output staging tile Os aliases Xs; when the weights are re-staged per chunk anyway (!SINGLE) it
+    // may also run over Ws, otherwise Xs is sized to hold it.
+    constexpr int XS_ELEMS = (SINGLE && TH * TW * OP > NPIX * CKP) ? TH * TW * OP : NPIX * CKP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* Xs = reinterpret_cast<T*>(smem_raw);
-    constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3;   // strides / dilations are compile-time: all tile index math folds
-    T* Ws = Xs + (long)IH * IW * CKP;
+    T* Os = Xs;
+    T* Ws = Xs + XS_ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, n0 = blockIdx.y * NT;
-    const int th = blockIdx.x / a.tiles_w, tw = blockIdx.x % a.tiles_w;
-    const int oh0 = th * TH, ow0 = tw * TW;
-    const int vh0 = oh0 * SH - 1, vw0 = ow0 * SW - 1;           // virtual (dilated) input origin of the halo
+    const int n0 = blockIdx.y * NT;
     const int Hv = (a.Hr - 1) * DH + 1, Wv = (a.Wr - 1) * DW + 1;
-    const T* X = (const T*)a.x + (long)b * a.Hr * a.Wr * a.CIN;
     const T* W = (const T*)a.w;
+    constexpr bool single = SINGLE;   // the whole reduction is one channel chunk: weights staged once per block
+    const int frow = lane & 31, fk = (lane >> 5) * VEC, hsel = 4 * (lane >> 5);
 
-    f32x16 acc[RPW][NB];
+    auto stage_weights = [&](int c0) {      // Ws[n][tap][k] for channel chunk c0; one 16-byte chunk per thread per round
+        constexpr int NCH = NT * 9 * CPP, ROUNDS = (NCH + 255) / 256;
+        F v[ROUNDS];
 #pragma unroll
-    for (int i = 0; i < RPW; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int frow = lane & 31, fk = (lane >> 5) * VEC;
-    constexpr int CPP = CK / VEC;  // 16-byte chunks per pixel per channel chunk
-    // staging walks the halo with a fixed per-thread channel chunk and an incremental (row, col): no divisions in the loop
-    constexpr int DP = 256 / CPP;                 // halo pixels advanced per iteration
-    constexpr int di = DP / IW, dj = DP % IW;
-    const int pix0 = tid / CPP, kc0 = (tid % CPP) * VEC;
-    const int il0 = pix0 / IW, jl0 = pix0 % IW;
-    constexpr int mh = DH - 1, mw = DW - 1, shh = DH >> 1, shw = DW >> 1;   // dilation is 1 or 2
-    constexpr int npix = IH * IW;
-
-    for (int c0 = 0; c0 < a.CIN; c0 += CK) {
-        __syncthreads();
-        // ---- stage the input halo (zero outside the image and on dilation holes)
-        staged_walk<6, F>(pix0, npix, DP, il0, jl0, di, dj, IW,
-            [&](int il, int jl) -> F {
-                const int vh = vh0 + il, vw = vw0 + jl;
-                F v = frag_zero<T>();
-                if (vh >= 0 && vh < Hv && vw >= 0 && vw < Wv && (vh & mh) == 0 && (vw & mw) == 0) {
-                    const int ih = vh >> shh, iw = vw >> shw;
-                    v = *reinterpret_cast<const F*>(X + ((long)ih * a.Wr + iw) * a.CIN + c0 + kc0);
-                    if (a.mean) {
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            const int ch = b * a.CIN + c0 + kc0 + e;
-                            v[e] = from_f32<T>((to_f32(v[e]) - a.mean[ch]) * a.rstd[ch]);
-                        }
-                    }
-                }
-                return v;
-            },
-            [&](int pix, const F& v) { *reinterpret_cast<F*>(Xs + (long)pix * CKP + kc0) = v; });
-        // ---- stage the weights of this channel chunk: Ws[n][tap][k]  (rows = n*9 + tap; batched loads)
-        {
-            constexpr int NROW = NT * 9, GW = 5;
-            for (int base = pix0; base < NROW; base += GW * DP) {
-                F v[GW];
-#pragma unroll
-                for (int g = 0; g < GW; ++g) {
-                    const int row = base + g * DP;
-                    const int n = n0 + row / 9;
-                    v[g] = frag_zero<T>();
-                    if (row < NROW && n < a.COUT) v[g] = *reinterpret_cast<const F*>(W + ((long)n * 9 + row % 9) * a.CIN + c0 + kc0);
-                }
-#pragma unroll
-                for (int g = 0; g < GW; ++g) {
-                    const int row = base + g * DP;
-                    if (row < NROW) *reinterpret_cast<F*>(Ws + (long)row * CKP + kc0) = v[g];
-                }
-            }
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int c = tid + r * 256, row = c / CPP, kc = (c % CPP) * VEC, n = n0 + row / 9;
+            v[r] = frag_zero<T>();
+            if (c < NCH && n < a.COUT) v[r] = *reinterpret_cast<const F*>(W + ((long)n * 9 + row % 9) * a.CIN + c0 + kc);
         }
-        __syncthreads();
-        // ---- nine shifted GEMMs out of LDS
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap % 3;
-#pragma unroll
-            for (int kk = 0; kk < CK; kk += KStep<T>::value) {
-                F af[RPW], bf[NB];
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) {
-                    const int r = wave * RPW + i;
-                    const int pix = (r * SH + kh) * IW + frow * SW + kw;
-                    af[i] = *reinterpret_cast<const F*>(Xs + (long)pix * CKP + kk + fk);
-                }
-#pragma unroll
-                for (int j = 0; j < NB; ++j)
-                    bf[j] = *reinterpret_cast<const F*>(Ws + (long)((j * 32 + frow) * 9 + tap) * CKP + kk + fk);
-#pragma unroll
-                for (int i = 0; i < RPW; ++i)
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) mma32(acc[i][j], af[i], bf[j]);
-            }
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int c = tid + r * 256, row = c / CPP, kc = (c % CPP) * VEC;
+            if (c < NCH) *reinterpret_cast<F*>(Ws + (long)row * CKP + kc) = v[r];
         }
-    }
+    };
 
-    // ---- epilogue: bias + ReLU in registers, tile staged through LDS, then 16-byte coalesced stores (+ optional mask).
-    // (Storing 8-byte runs straight from a transposed accumulator was measured 15 % slower: partial-line writes.)
-    __syncthreads();                              // every wave is done with Xs / Ws: reuse the space
-    constexpr int OP = NT + VEC;                  // output-tile pitch (elements)
-    T* Os = reinterpret_cast<T*>(smem_raw);
+    // per-lane bias values for the 16 couts of each cout block (constant for the whole kernel)
+    float bv[NB][16];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int nl = j * 32 + (lane & 31);
-        const float bv = (a.bias && n0 + nl < a.COUT) ? a.bias[n0 + nl] : 0.f;
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + j * 32 + (r & 3) + 8 * (r >> 2) + hsel;
+            bv[j][r] = (a.bias && n < a.COUT) ? a.bias[n] : 0.f;
+        }
+
+    if (single) stage_weights(0);
+
+    const int tiles_per_img = a.tiles_h * a.tiles_w, ntiles = a.B * tiles_per_img;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
+        const int th = rem / a.tiles_w, tw = rem - th * a.tiles_w;
+        const int oh0 = th * TH, ow0 = tw * TW;
+        const int vh0 = oh0 * SH - 1, vw0 = ow0 * SW - 1;           // virtual (dilated) input origin of the halo
+        const T* X = (const T*)a.x + (long)b * a.Hr * a.Wr * a.CIN;
+
+        f32x16 acc[RPW][NB];
 #pragma unroll
         for (int i = 0; i < RPW; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[i][j][r] + bv;
-                if (a.relu) v = fmaxf(v, 0.f);
-                Os[(long)((wave * RPW + i) * TW + acc_row(r, lane)) * OP + nl] = from_f32<T>(v);
-            }
-    }
-    __syncthreads();
-    T* Y = (T*)a.y + (long)b * a.Ho * a.Wo * a.COUT;
-    const T* Mk = a.mask ? (const T*)a.mask + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
-    constexpr int CPO = NT / VEC;
-    for (int c = tid; c < TH * TW * CPO; c += 256) {
-        const int pl = c / CPO, kc = (c % CPO) * VEC;
-        const int oh = oh0 + pl / TW, ow = ow0 + pl % TW, n = n0 + kc;
-        if (oh >= a.Ho || ow >= a.Wo || n >= a.COUT) continue;
-        F v = *reinterpret_cast<const F*>(Os + (long)pl * OP + kc);
-        const long o = ((long)oh * a.Wo + ow) * a.COUT + n;
-        if (Mk) {
-            const F m = *reinterpret_cast<const F*>(Mk + o);
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) v[e] = from_f32<T>(to_f32(m[e]) > 0.f ? to_f32(v[e]) * a.mask_scale : 0.f);
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int c0 = 0; c0 < a.CIN; c0 += CK) {
+            __syncthreads();                  // previous tile's store loop / previous chunk's MFMAs are done with Xs (and Ws)
+            // ---- stage the input halo: thread = one halo pixel per round (ONE bounds test + address for its CPP chunks:
+            //      measured 30 % faster than chunk-granular staging on the 16/32-channel layers, which are VALU-limited);
+            //      all loads of all rounds are issued before the first LDS store
+            {
+                constexpr int ROUNDS = (NPIX + 255) / 256;
+                F v[ROUNDS][CPP];
+#pragma unroll
+                for (int r = 0; r < ROUNDS; ++r) {
+                    const int pix = tid + r * 256;
+                    const int il = pix / IW, jl = pix - il * IW;
+                    const int vh = vh0 + il, vw = vw0 + jl;
+                    const bool ok = pix < NPIX && vh >= 0 && vh < Hv && vw >= 0 && vw < Wv && (vh & (DH - 1)) == 0 && (vw & (DW - 1)) == 0;
+                    const T* src = X + ((long)(vh >> (DH >> 1)) * a.Wr + (vw >> (DW >> 1))) * a.CIN + c0;
+#pragma unroll
+                    for (int k = 0; k < CPP; ++k) {
+                        v[r][k] = frag_zero<T>();
+                        if (ok) v[r][k] = *reinterpret_cast<const F*>(src + k * VEC);
+                    }
+                    if (ok && a.mean) {
+#pragma unroll
+                        for (int k = 0; k < CPP; ++k)
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) {
+                                const int ch = b * a.CIN + c0 + k * VEC + e;
+                                v[r][k][e] = from_f32<T>((to_f32(v[r][k][e]) - a.mean[ch]) * a.rstd[ch]);
+                            }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < ROUNDS; ++r) {
+                    const int pix = tid + r * 256;
+                    if (pix < NPIX)
+#pragma unroll
+                        for (int k = 0; k < CPP; ++k) *reinterpret_cast<F*>(Xs + (long)pix * CKP + k * VEC) = v[r][k];
+                }
+            }
+            if (!single) stage_weights(c0);
+            __syncthreads();
+            // ---- nine shifted GEMMs out of LDS
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+                for (int kk = 0; kk < CK; kk += KStep<T>::value) {
+                    F af[RPW], bf[NB];
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i) {
+                        const int pix = ((wave * RPW + i) * SH + kh) * IW + frow * SW + kw;
+                        af[i] = *reinterpret_cast<const F*>(Xs + (long)pix * CKP + kk + fk);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        bf[j] = *reinterpret_cast<const F*>(Ws + (long)((j * 32 + frow) * 9 + tap) * CKP + kk + fk);
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) mma32(acc[i][j], bf[j], af[i]);   // D[cout][pixel]
+                }
+            }
         }
-        *reinterpret_cast<F*>(Y + o) = v;
+
+        // ---- epilogue
+        __syncthreads();                              // every wave is done reading Xs: Os aliases it
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                T* orow = Os + (long)((wave * RPW + i) * TW + frow) * OP + j * 32 + hsel;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    T4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][4 * g + e] + bv[j][4 * g + e];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        o[e] = from_f32<T>(v);
+                    }
+                    *reinterpret_cast<T4*>(orow + 8 * g) = o;
+                }
+            }
+        __syncthreads();
+        T* Y = (T*)a.y + (long)b * a.Ho * a.Wo * a.COUT;
+        const T* Mk = a.mask ? (const T*)a.mask + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
+        constexpr int CPO = NT / VEC;
+#pragma unroll
+        for (int c = tid; c < TH * TW * CPO; c += 256) {
+            const int pl = c / CPO, kc = (c % CPO) * VEC;
+            const int oh = oh0 + pl / TW, ow = ow0 + pl % TW, n = n0 + kc;
+            if (oh >= a.Ho || ow >= a.Wo || n >= a.COUT) continue;
+            F v = *reinterpret_cast<const F*>(Os + (long)pl * OP + kc);
+            const long o = ((long)oh * a.Wo + ow) * a.COUT + n;
+            if (Mk) {
+                const F m = *reinterpret_cast<const F*>(Mk + o);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = from_f32<T>(to_f32(m[e]) > 0.f ? to_f32(v[e]) * a.mask_scale : 0.f);
+            }
+            *reinterpret_cast<F*>(Y + o) = v;
+        }
     }
 }
 
-template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW> int launch_conv(const ConvArgs& a0, hipStream_t s) {
+template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, bool SINGLE> int launch_conv2(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     constexpr int TH = 4 * RPW;
     constexpr int CKP = CK + Frag<T>::N;
-    constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3;
+    constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3, NPIX = IH * IW, OP = NT + Frag<T>::N;
+    constexpr int XS_ELEMS = (SINGLE && TH * TW * OP > NPIX * CKP) ? TH * TW * OP : NPIX * CKP;
     a.tiles_w = cdiv(a.Wo, TW);
     a.tiles_h = cdiv(a.Ho, TH);
-    size_t shm = ((size_t)IH * IW + (size_t)NT * 9) * CKP * sizeof(T);
-    const size_t shm_out = (size_t)TH * TW * (NT + Frag<T>::N) * sizeof(T);   // epilogue staging reuses the same space
-    if (shm_out > shm) shm = shm_out;
+    size_t shm = ((size_t)XS_ELEMS + (size_t)NT * 9 * CKP) * sizeof(T);
+    if (!SINGLE && (size_t)TH * TW * OP * sizeof(T) > shm) shm = (size_t)TH * TW * OP * sizeof(T);
     if (shm > 160 * 1024) return OMR_ERR_UNSUPPORTED;
     if (a.COUT % Frag<T>::N) return OMR_ERR_UNSUPPORTED;
-    auto kern = conv3x3_mfma_kernel<T, NT, RPW, CK, SH, SW, DH, DW>;
+    auto kern = conv3x3_mfma_kernel<T, NT, RPW, CK, SH, SW, DH, DW, SINGLE>;
     if (shm > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return OMR_ERR_LAUNCH;
     }
-    dim3 grid(a.tiles_w * a.tiles_h, cdiv(a.COUT, NT), a.B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), shm, s, a);
+    const int ny = cdiv(a.COUT, NT);
+    const long ntiles = (long)a.B * a.tiles_w * a.tiles_h;
+    long gx = 2048 / ny;                           // persistent: ~8 blocks per CU worth of slots, grid-stride over tiles
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, ny, 1), dim3(256), shm, s, a);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
+}
+
+template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW> int launch_conv(const ConvArgs& a, hipStream_t s) {
+    if (a.CIN == CK) return launch_conv2<T, NT, RPW, CK, SH, SW, DH, DW, true>(a, s);
+    return launch_conv2<T, NT, RPW, CK, SH, SW, DH, DW, false>(a, s);
 }
 
 // stride / dilation combinations the encoder needs: forward (1,1) (2,2) (2,1); data gradient = stride 1 with dilation (2,2) / (2,1)
