@@ -1,14 +1,21 @@
 // Generic MFMA GEMM for gfx950:  C[M,N] (+)= act( opA(A) . opB(B)^T + bias[N] )
 //
-// Canonical ("NT") operand form: A is [M][K] and B is [N][K], both k-contiguous.  transA / transB
-// mean the operand is stored reduction-major instead ([K][M] / [K][N]); the tile is transposed
-// while it is staged into LDS so the MFMA fragment reads are always 16-byte k-contiguous.
+// Canonical ("NT") operand form: A is [M][K] and B is [N][K], both k-contiguous.  transA / transB mean the operand is
+// stored reduction-major instead ([K][M] / [K][N]).
 //   linear forward      Y  = X  . W^T + b      (NT)            torch nn/modules/transformer.py:1158-1199
 //   linear input grad   dX = dY . W            (transB)
-//   linear weight grad  dW = dY^T . X          (transA+transB, split-K, fp32 atomic accumulate)
+//   linear weight grad  dW = dY^T . X          (transA+transB, split-K, fp32 atomic accumulate; db = column sums of dY fused)
 //   1x1 "point_conv" of DepthSepConv2D (encoder.py:65-70) on NHWC activations = the same GEMMs
 //   Conv1d(k=1) head (decoder.py:98-102)       = the same GEMM with N = vocabulary
-// Block tile 128x128, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 blocks; BK = 2 k-steps.
+// Block tile 128x128, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 blocks; BK = 4 k-steps (64 bf16 / 32 fp32).
+// Operand staging: global -> registers (prefetch of tile t+1 issued before the MFMAs of tile t) -> LDS.
+//   k-contiguous operands : [rows][BK] with a 16-byte odd-multiple pitch, fragments = ds_read_b128
+//   reduction-major bf16   : staged untransposed [BK][rows], fragments = ds_read_b64_tr_b16 (no transposing stores)
+//   reduction-major fp32   : transposed while stored (parity path only)
+// Epilogue (bf16 C): the MFMA is issued with swapped operands so a lane holds runs of 4 consecutive columns, the wave's
+// 64x64 tile goes through LDS (8-byte stores) and leaves as 16-byte row-contiguous global stores.  The fp32 / atomic
+// (dW) epilogue keeps columns on lanes: one wave instruction then covers 128 contiguous bytes per row, the shape global
+// float atomics want.
 #include <type_traits>
 
 #include "omr_common.h"
@@ -27,13 +34,16 @@ constexpr int BM = 128, BN = 128;
 
 template <typename T> struct GemmCfg {
     static constexpr int VEC = Frag<T>::N;
-    static constexpr int BK = 2 * KStep<T>::value;          // 32 (bf16) / 16 (fp32): 64 B per row
-    static constexpr int PITCH = BK + VEC;                   // 80 B pitch: conflict-free b128 reads
-    static constexpr int CHUNKS_PER_ROW = BK / VEC;          // 4
-    // reduction-major bf16 operands are staged as they lie in HBM ([k][128 rows]) and read with ds_read_b64_tr_b16:
-    // pitch = 16 dwords mod 64 so the 4 k-rows of a transposing read tile all 64 banks.
+    static constexpr int BK = 4 * KStep<T>::value;           // 64 (bf16) / 32 (fp32): 128 B per row
+    static constexpr int PITCH = BK + VEC;                   // 144 B pitch: conflict-free b128 reads
+    static constexpr int CHUNKS_PER_ROW = BK / VEC;          // 8
+    static constexpr int NCH = BM * BK / VEC / 256;          // 16-byte chunks per thread per operand tile (4)
+    // reduction-major bf16 operands stay [k][128 rows]; pitch = 16 dwords mod 64 so the 4 k-rows of a transposing read
+    // tile all 64 banks
     static constexpr int TPITCH = 128 + 32;
-    static constexpr int LDS_ELEMS = (BM * PITCH > BK * TPITCH) ? BM * PITCH : BK * TPITCH;
+    static constexpr int OP_ELEMS = (BM * PITCH > BK * TPITCH) ? BM * PITCH : BK * TPITCH;
+    static constexpr int CPITCH = 64 + 8;                    // per-wave 64x64 output staging tile (bf16 C)
+    static constexpr int LDS_ELEMS = (2 * OP_ELEMS > 4 * 64 * CPITCH) ? 2 * OP_ELEMS : 4 * 64 * CPITCH;
 };
 template <typename T, bool TR> struct UseTrRead { static constexpr bool value = TR && std::is_same<T, bf16>::value; };
 
@@ -51,38 +61,37 @@ template <typename T> __device__ __forceinline__ typename Frag<T>::type load_chu
     return v;
 }
 
-// Stage one operand tile (rows x BK) into LDS.  TR=false: src is [rows][K] k-contiguous.
-// TR=true: src is [K][rows] (rows contiguous).  Two 16-byte chunks per thread.
+// Stage one operand tile (128 rows x BK) into LDS.  TR=false: src is [rows][K] k-contiguous; TR=true: src is [K][rows].
 template <typename T, bool TR> struct Stager {
     typedef GemmCfg<T> Cfg;
     typedef typename Frag<T>::type F;
-    F r[2];
+    F r[Cfg::NCH];
     __device__ __forceinline__ void load(const T* src, long ld, int row0, int nrows, int k0, int kend, int tid) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int c = tid + i * 256;
+        for (int i = 0; i < Cfg::NCH; ++i) {
+            const int c = tid + i * 256;
             if (!TR) {
-                int row = c / Cfg::CHUNKS_PER_ROW, kc = (c % Cfg::CHUNKS_PER_ROW) * Cfg::VEC;
-                int gr = row0 + row, gk = k0 + kc;
+                const int row = c / Cfg::CHUNKS_PER_ROW, kc = (c % Cfg::CHUNKS_PER_ROW) * Cfg::VEC;
+                const int gr = row0 + row, gk = k0 + kc;
                 r[i] = (gr < nrows) ? load_chunk_guard<T>(src + (long)gr * ld + gk, kend - gk) : frag_zero<T>();
             } else {
                 constexpr int CPR = 128 / Cfg::VEC;  // chunks along the 128 tile rows, per k
-                int k = c / CPR, rc = (c % CPR) * Cfg::VEC;
-                int gk = k0 + k, gr = row0 + rc;
+                const int k = c / CPR, rc = (c % CPR) * Cfg::VEC;
+                const int gk = k0 + k, gr = row0 + rc;
                 r[i] = (gk < kend) ? load_chunk_guard<T>(src + (long)gk * ld + gr, nrows - gr) : frag_zero<T>();
             }
         }
     }
     __device__ __forceinline__ void store(T* lds, int tid) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int c = tid + i * 256;
+        for (int i = 0; i < Cfg::NCH; ++i) {
+            const int c = tid + i * 256;
             if (!TR) {
-                int row = c / Cfg::CHUNKS_PER_ROW, kc = (c % Cfg::CHUNKS_PER_ROW) * Cfg::VEC;
+                const int row = c / Cfg::CHUNKS_PER_ROW, kc = (c % Cfg::CHUNKS_PER_ROW) * Cfg::VEC;
                 *reinterpret_cast<F*>(lds + row * Cfg::PITCH + kc) = r[i];
             } else {
                 constexpr int CPR = 128 / Cfg::VEC;
-                int k = c / CPR, rc = (c % CPR) * Cfg::VEC;
+                const int k = c / CPR, rc = (c % CPR) * Cfg::VEC;
                 if constexpr (UseTrRead<T, TR>::value) {
                     *reinterpret_cast<F*>(lds + k * Cfg::TPITCH + rc) = r[i];     // untransposed; fragments come from tr reads
                 } else {
@@ -92,16 +101,16 @@ template <typename T, bool TR> struct Stager {
             }
         }
     }
-    // per-thread column sums of the staged chunks (TR only): chunk i covers columns rc..rc+VEC-1 of k-row k
+    // per-thread column sums of the staged chunks (TR only): every chunk of this thread covers the same VEC tile rows
     __device__ __forceinline__ void add_colsum(float (&cs)[Cfg::VEC]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < Cfg::NCH; ++i)
 #pragma unroll
             for (int e = 0; e < Cfg::VEC; ++e) cs[e] += to_f32(r[i][e]);
     }
 };
 
-// Operand fragment for output-row block starting at `row0` (32 rows) and k-step `ks` of the current tile.
+// Operand fragment for the 32 output rows starting at `row0` and k-step `ks` of the current tile.
 template <typename T, bool TR>
 __device__ __forceinline__ typename Frag<T>::type load_frag(const T* lds, int row0, int ks, int lane) {
     typedef GemmCfg<T> Cfg;
@@ -122,8 +131,10 @@ template <typename T, typename TC, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     typedef GemmCfg<T> Cfg;
     typedef typename Frag<T>::type F;
-    __shared__ __attribute__((aligned(16))) T As[Cfg::LDS_ELEMS];
-    __shared__ __attribute__((aligned(16))) T Bs[Cfg::LDS_ELEMS];
+    constexpr bool SWAP = std::is_same<TC, bf16>::value;     // bf16 output: transposed accumulators + LDS-staged stores
+    __shared__ __attribute__((aligned(16))) T smem[Cfg::LDS_ELEMS];
+    T* As = smem;
+    T* Bs = smem + Cfg::OP_ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -170,7 +181,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mma32(acc[i][j], a[i], b[j]);
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (SWAP) mma32(acc[i][j], b[j], a[i]);     // D[n][m]: lane = row m, registers = columns n
+                    else mma32(acc[i][j], a[i], b[j]);                     // D[m][n]: lane = column n
+                }
         }
         __syncthreads();
         if (more) {
@@ -181,10 +195,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
     }
 
-    if (do_cs) {   // this thread's chunks always cover the same VEC output rows m0 + (tid % CPR) * VEC: combine the 256
-                   // per-thread partials in LDS (As is free after the last barrier), then ONE global atomic per row per block
+    if (do_cs) {   // combine the 256 per-thread partials in LDS (operand tiles are dead), then ONE global atomic per row per block
         constexpr int CPR = 128 / Cfg::VEC;
-        float* red = reinterpret_cast<float*>(As);
+        float* red = reinterpret_cast<float*>(smem);
         if (tid < 128) red[tid] = 0.f;
         __syncthreads();
         const int ml = (tid % CPR) * Cfg::VEC;
@@ -192,29 +205,79 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int e = 0; e < Cfg::VEC; ++e) atomicAdd(&red[ml + e], cs[e]);
         __syncthreads();
         if (tid < 128 && m0 + tid < g.M) atomicAdd(&g.colsum_a[m0 + tid], red[tid]);
+        __syncthreads();
     }
+
     TC* C = (TC*)g.C;
-    const int col_l = lane & 31;
+    if constexpr (SWAP) {
+        // ---- bf16 C: lane = row (lane & 31) of M-block i; register r = column (r&3) + 8(r>>2) + 4(lane>>5) of N-block j
+        typedef __attribute__((ext_vector_type(4))) bf16 B4;
+        T* Cs = smem + wave * (64 * Cfg::CPITCH);          // all waves passed the last barrier: operand tiles are dead
+        const int hsel = 4 * (lane >> 5);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + col_l;
-        if (col >= g.N) continue;
-        const float bv = (g.bias != nullptr && blockIdx.z == 0) ? g.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < 2; ++j) {
+            float bv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
-                if (row >= g.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (g.relu) v = fmaxf(v, 0.f);
-                TC* dst = C + (long)row * g.ldc + col;
-                if (g.atomic) {
-                    if constexpr (sizeof(TC) == 4) atomicAdd((float*)dst, v);
-                } else if (g.accum) {
-                    *dst = from_f32<TC>(to_f32(*dst) + v);
-                } else {
-                    *dst = from_f32<TC>(v);
+                const int col = n0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + hsel;
+                bv[r] = (g.bias != nullptr && blockIdx.z == 0 && col < g.N) ? g.bias[col] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                T* crow = Cs + (i * 32 + (lane & 31)) * Cfg::CPITCH + j * 32 + hsel;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    B4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][4 * q + e] + bv[4 * q + e];
+                        if (g.relu) v = fmaxf(v, 0.f);
+                        o[e] = (bf16)v;
+                    }
+                    *reinterpret_cast<B4*>(crow + 8 * q) = o;
+                }
+            }
+        }
+        // same-wave LDS writes are ordered before the reads below (in-order LDS queue); no block barrier needed
+        const bool vec_ok = (g.ldc % 8) == 0 && (((uintptr_t)C) & 15) == 0;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int c = lane + it * 64, row = c >> 3, kc = (c & 7) * 8;
+            const int gr = m0 + wm * 64 + row, gc = n0 + wn * 64 + kc;
+            if (gr >= g.M || gc >= g.N) continue;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * Cfg::CPITCH + kc);
+            TC* dst = C + (long)gr * g.ldc + gc;
+            if (vec_ok && gc + 8 <= g.N && !g.accum) {
+                *reinterpret_cast<bf16x8*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (gc + e < g.N) dst[e] = g.accum ? (bf16)((float)dst[e] + (float)v[e]) : v[e];
+            }
+        }
+    } else {
+        const int col_l = lane & 31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + col_l;
+            if (col >= g.N) continue;
+            const float bv = (g.bias != nullptr && blockIdx.z == 0) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                    if (row >= g.M) continue;
+                    float v = acc[i][j][r] + bv;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    TC* dst = C + (long)row * g.ldc + col;
+                    if (g.atomic) {
+                        if constexpr (sizeof(TC) == 4) atomicAdd((float*)dst, v);
+                    } else if (g.accum) {
+                        *dst = from_f32<TC>(to_f32(*dst) + v);
+                    } else {
+                        *dst = from_f32<TC>(v);
+                    }
                 }
             }
         }
@@ -246,7 +309,7 @@ extern "C" int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, i
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.relu = relu; g.accum = accumulate; g.atomic = split_k > 1; g.colsum_a = colsum_a;
     if (colsum_a && !transA) return OMR_ERR_ARG;
-    const int bk = dtype == OMR_BF16 ? 32 : 16;
+    const int bk = dtype == OMR_BF16 ? 64 : 32;
     int len = cdiv(cdiv(K, split_k), bk) * bk;
     g.ksplit_len = len;
     int splits = cdiv(K, len);
