@@ -315,7 +315,7 @@ struct WgradArgs {
     int B, Hr, Wr, CIN, Ho, Wo, COUT, sh, sw, tiles_w, tiles_h;
 };
 
-template <typename T, int TH, int CBN, int CBC>
+template <typename T, int TH, int CBN, int CBC, int SH, int SW>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     typedef typename Frag<T>::type F;
     constexpr int VEC = Frag<T>::N;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     constexpr int NP = TR ? (CBN == 32 ? 32 : 96) : CBN + 4, CP = TR ? (CBC == 32 ? 32 : 96) : CBC + 4;
     typedef __attribute__((address_space(3))) bf16x4 LdsV4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int IH = (TH - 1) * a.sh + 3, IW = (TW - 1) * a.sw + 3;
+    constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3, NPIX = IH * IW;   // compile-time tile geometry
     T* Ys = reinterpret_cast<T*>(smem_raw);            // [TH*TW][NP]
     T* Xs = Ys + (long)TH * TW * NP;                   // [IH*IW][CP]
 
@@ -341,8 +341,6 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const int dix = (256 / (CBC / VEC)) / IW, djx = (256 / (CBC / VEC)) % IW;   // halo staging increments (pixels per pass)
-    const int il0x = (tid / (CBC / VEC)) / IW, jl0x = (tid / (CBC / VEC)) % IW;
     const int ntiles = a.B * a.tiles_h * a.tiles_w;
     const bool do_bias = a.db != nullptr && (blockIdx.y % ncb) == 0;   // one cin-block column of the grid owns the bias sums
     float bsum = 0.f;
@@ -350,43 +348,64 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
         const int b = tile / (a.tiles_h * a.tiles_w);
         const int rem = tile % (a.tiles_h * a.tiles_w);
         const int oh0 = (rem / a.tiles_w) * TH, ow0 = (rem % a.tiles_w) * TW;
-        const int ih0 = oh0 * a.sh - 1, iw0 = ow0 * a.sw - 1;
+        const int ih0 = oh0 * SH - 1, iw0 = ow0 * SW - 1;
         const T* X = (const T*)a.x + (long)b * a.Hr * a.Wr * a.CIN;
         const T* DY = (const T*)a.dy + (long)b * a.Ho * a.Wo * a.COUT;
         __syncthreads();
-        // ---- stage dY tile [pix][CBN] and X halo [pix][CBC] (batched 16-byte loads, incremental indices)
+        // ---- stage dY tile [pix][CBN] and X halo [pix][CBC]: thread = one pixel per round (one bounds test + address for
+        //      all of its 16-byte chunks); every load of every round is issued before the first LDS store
         {
-            constexpr int CPN = CBN / VEC, DPN = 256 / CPN;
-            const int kc = (tid % CPN) * VEC;
-            staged_walk<4, F>(tid / CPN, TH * TW, DPN, (tid / CPN) / TW, (tid / CPN) % TW, DPN / TW, DPN % TW, TW,
-                [&](int il, int jl) -> F {
-                    const int oh = oh0 + il, ow = ow0 + jl;
-                    F v = frag_zero<T>();
-                    if (oh < a.Ho && ow < a.Wo && n0 + kc < a.COUT) v = *reinterpret_cast<const F*>(DY + ((long)oh * a.Wo + ow) * a.COUT + n0 + kc);
-                    return v;
-                },
-                [&](int pix, const F& v) { *reinterpret_cast<F*>(Ys + (long)pix * NP + kc) = v; });
-        }
-        {
-            constexpr int CPC = CBC / VEC, DPC = 256 / CPC;
-            const int kc = (tid % CPC) * VEC;
-            staged_walk<6, F>(tid / CPC, IH * IW, DPC, il0x, jl0x, dix, djx, IW,
-                [&](int il, int jl) -> F {
-                    const int ih = ih0 + il, iw = iw0 + jl;
-                    F v = frag_zero<T>();
-                    if (ih >= 0 && ih < a.Hr && iw >= 0 && iw < a.Wr && c0 + kc < a.CIN) {
-                        v = *reinterpret_cast<const F*>(X + ((long)ih * a.Wr + iw) * a.CIN + c0 + kc);
-                        if (a.mean) {
+            constexpr int CPN = CBN / VEC, CPC = CBC / VEC;
+            constexpr int RY = (TH * TW + 255) / 256, RX = (NPIX + 255) / 256;
+            F vy[RY][CPN], vx[RX][CPC];
 #pragma unroll
-                            for (int e = 0; e < VEC; ++e) {
-                                const int ch = b * a.CIN + c0 + kc + e;
-                                v[e] = from_f32<T>((to_f32(v[e]) - a.mean[ch]) * a.rstd[ch]);
-                            }
+            for (int r = 0; r < RY; ++r) {
+                const int pix = tid + r * 256;
+                const int oh = oh0 + pix / TW, ow = ow0 + pix % TW;
+                const bool ok = pix < TH * TW && oh < a.Ho && ow < a.Wo;
+                const T* src = DY + ((long)oh * a.Wo + ow) * a.COUT + n0;
+#pragma unroll
+                for (int k = 0; k < CPN; ++k) {
+                    vy[r][k] = frag_zero<T>();
+                    if (ok && n0 + k * VEC < a.COUT) vy[r][k] = *reinterpret_cast<const F*>(src + k * VEC);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RX; ++r) {
+                const int pix = tid + r * 256;
+                const int il = pix / IW, jl = pix - il * IW;
+                const int ih = ih0 + il, iw = iw0 + jl;
+                const bool ok = pix < NPIX && ih >= 0 && ih < a.Hr && iw >= 0 && iw < a.Wr;
+                const T* src = X + ((long)ih * a.Wr + iw) * a.CIN + c0;
+#pragma unroll
+                for (int k = 0; k < CPC; ++k) {
+                    vx[r][k] = frag_zero<T>();
+                    if (ok && c0 + k * VEC < a.CIN) vx[r][k] = *reinterpret_cast<const F*>(src + k * VEC);
+                }
+                if (ok && a.mean) {
+#pragma unroll
+                    for (int k = 0; k < CPC; ++k)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const int ch = c0 + k * VEC + e;
+                            if (ch < a.CIN) vx[r][k][e] = from_f32<T>((to_f32(vx[r][k][e]) - a.mean[b * a.CIN + ch]) * a.rstd[b * a.CIN + ch]);
                         }
-                    }
-                    return v;
-                },
-                [&](int pix, const F& v) { *reinterpret_cast<F*>(Xs + (long)pix * CP + kc) = v; });
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                const int pix = tid + r * 256;
+                if (pix < TH * TW)
+#pragma unroll
+                    for (int k = 0; k < CPN; ++k) *reinterpret_cast<F*>(Ys + (long)pix * NP + k * VEC) = vy[r][k];
+            }
+#pragma unroll
+            for (int r = 0; r < RX; ++r) {
+                const int pix = tid + r * 256;
+                if (pix < NPIX)
+#pragma unroll
+                    for (int k = 0; k < CPC; ++k) *reinterpret_cast<F*>(Xs + (long)pix * CP + k * VEC) = vx[r][k];
+            }
         }
         __syncthreads();
         if (do_bias) {   // bias gradient: column sums of the staged dY tile (thread = channel x pixel phase)
@@ -405,13 +424,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
                 const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(Ys + (long)(pk + 4) * NP + wn * 32 + chan));
                 const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                 const int r = pk >> 5, col = pk & 31;
-                const T* xrow = Xs + (long)((r * a.sh) * IW + col * a.sw) * CP + wc * 32 + chan;
+                const T* xrow = Xs + (long)((r * SH) * IW + col * SW) * CP + wc * 32 + chan;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int kh = tap / 3, kw = tap % 3;
                     const T* xp = xrow + (long)(kh * IW + kw) * CP;
                     const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)xp);
-                    const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(xp + (long)4 * a.sw * CP));
+                    const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(xp + (long)4 * SW * CP));
                     const bf16x8 bf = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
                     mma32(acc[tap], af, bf);
                 }
@@ -429,7 +448,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
                     const int kh = tap / 3, kw = tap % 3;
                     F bf;
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) bf[e] = Xs[(long)((r * a.sh + kh) * IW + (col + e) * a.sw + kw) * CP + cl];
+                    for (int e = 0; e < VEC; ++e) bf[e] = Xs[(long)((r * SH + kh) * IW + (col + e) * SW + kw) * CP + cl];
                     mma32(acc[tap], af, bf);
                 }
             }
@@ -452,15 +471,15 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     }
 }
 
-template <typename T, int TH, int CBN, int CBC> int launch_wgrad2(WgradArgs a, hipStream_t s) {
+template <typename T, int TH, int CBN, int CBC, int SH, int SW> int launch_wgrad3(WgradArgs a, hipStream_t s) {
     a.tiles_w = cdiv(a.Wo, TW);
     a.tiles_h = cdiv(a.Ho, TH);
-    const int IH = (TH - 1) * a.sh + 3, IW = (TW - 1) * a.sw + 3;
+    constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3;
     constexpr bool TR = std::is_same<T, bf16>::value;
     constexpr int NP = TR ? (CBN == 32 ? 32 : 96) : CBN + 4, CP = TR ? (CBC == 32 ? 32 : 96) : CBC + 4;
     size_t shm = ((size_t)TH * TW * NP + (size_t)IH * IW * CP) * sizeof(T);
     if (shm > 160 * 1024) return OMR_ERR_UNSUPPORTED;
-    auto kern = conv3x3_wgrad_kernel<T, TH, CBN, CBC>;
+    auto kern = conv3x3_wgrad_kernel<T, TH, CBN, CBC, SH, SW>;
     if (shm > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return OMR_ERR_LAUNCH;
     }
@@ -472,10 +491,18 @@ template <typename T, int TH, int CBN, int CBC> int launch_wgrad2(WgradArgs a, h
     return OMR_OK;
 }
 
-template <typename T, int TH> int launch_wgrad(const WgradArgs& a, hipStream_t s) {
-    if (a.COUT > 32 && a.CIN > 32) return launch_wgrad2<T, TH, 64, 64>(a, s);
-    if (a.COUT > 32) return launch_wgrad2<T, TH, 64, 32>(a, s);
-    return launch_wgrad2<T, TH, 32, 32>(a, s);
+template <typename T, int TH, int SH, int SW> int launch_wgrad2(const WgradArgs& a, hipStream_t s) {
+    if (a.COUT > 32 && a.CIN > 32) return launch_wgrad3<T, TH, 64, 64, SH, SW>(a, s);
+    if (a.COUT > 32) return launch_wgrad3<T, TH, 64, 32, SH, SW>(a, s);
+    return launch_wgrad3<T, TH, 32, 32, SH, SW>(a, s);
+}
+
+// TH1: tile rows for stride 1, TH2: for the strided convs (bigger halo)
+template <typename T, int TH1, int TH2> int launch_wgrad(const WgradArgs& a, hipStream_t s) {
+    if (a.sh == 1 && a.sw == 1) return launch_wgrad2<T, TH1, 1, 1>(a, s);
+    if (a.sh == 2 && a.sw == 2) return launch_wgrad2<T, TH2, 2, 2>(a, s);
+    if (a.sh == 2 && a.sw == 1) return launch_wgrad2<T, TH2, 2, 1>(a, s);
+    return OMR_ERR_UNSUPPORTED;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -774,9 +801,8 @@ extern "C" int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float
     WgradArgs a;
     a.x = x; a.dy = dy; a.dw = dw; a.db = db; a.mean = in_mean; a.rstd = in_rstd; a.B = B; a.Hr = H; a.Wr = W; a.CIN = CIN; a.Ho = Ho; a.Wo = Wo;
     a.COUT = COUT; a.sh = stride_h; a.sw = stride_w; a.tiles_w = a.tiles_h = 0;
-    const bool strided = stride_h > 1 || stride_w > 1;
-    if (dtype == OMR_BF16) return strided ? launch_wgrad<bf16, 4>(a, s) : launch_wgrad<bf16, 8>(a, s);
-    if (dtype == OMR_F32) return strided ? launch_wgrad<float, 2>(a, s) : launch_wgrad<float, 4>(a, s);
+    if (dtype == OMR_BF16) return launch_wgrad<bf16, 8, 4>(a, s);
+    if (dtype == OMR_F32) return launch_wgrad<float, 4, 2>(a, s);
     return OMR_ERR_UNSUPPORTED;
 }
 
