@@ -130,17 +130,24 @@ class _Base(FlatModuleMixin, LightningModule):
         return d[token] if token in d else d[str(token)]
 
     @torch.no_grad()
-    def _greedy(self, memory: torch.Tensor, want_probs: bool = False):
+    def _greedy(self, memory: torch.Tensor, want_probs: bool = False, use_cache: bool = True):
         """Autoregressive loop of validation_step / get_pred_seq_and_pred_prob_seq (model.py:182-193,247-260):
-        bs=1, memory_len=None, argmax of the last-step logits, stop after <eos> or max_seq_len tokens."""
+        bs=1, memory_len=None, argmax of the last-step logits, stop after <eos> or max_seq_len tokens.
+        use_cache=True runs the KV-cached step (Decoder.decode_step); use_cache=False re-runs the whole prefix each step
+        exactly like the reference.  Both give the same tokens (tests/test_model_gpu.py)."""
         sos = self.w2i[SOS_TOKEN]
-        y_in = torch.full((1, 1), sos, dtype=torch.int64, device=memory.device)
+        tok = torch.full((1, 1), sos, dtype=torch.int64, device=memory.device)
+        y_in = tok
         yhat: List[str] = []
         probs: List[float] = []
+        state = self.decoder.init_decode(memory) if use_cache else None
         for _ in range(self.max_seq_len):
-            logits = self.decoder(tgt=y_in, memory=memory, memory_len=None)   # [1, V, t]
-            last = logits[0, :, -1]
-            last32 = K.cast(last.contiguous(), torch.float32) if last.dtype != torch.float32 else last.contiguous()
+            if use_cache:
+                last32 = self.decoder.decode_step(tok, state).contiguous()
+            else:
+                logits = self.decoder(tgt=y_in, memory=memory, memory_len=None)   # [1, V, t]
+                last = logits[0, :, -1]
+                last32 = K.cast(last.contiguous(), torch.float32) if last.dtype != torch.float32 else last.contiguous()
             idx, val = K.argmax(last32)
             token = int(idx.item())
             word = self._i2w(token)
@@ -149,7 +156,9 @@ class _Base(FlatModuleMixin, LightningModule):
                 probs.append(float(val.item()))
             if word == EOS_TOKEN:
                 break
-            y_in = torch.cat([y_in, idx.view(1, 1)], dim=1)
+            tok = idx.view(1, 1)
+            if not use_cache:
+                y_in = torch.cat([y_in, tok], dim=1)
         return yhat, probs
 
     @torch.no_grad()

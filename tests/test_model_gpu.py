@@ -205,6 +205,10 @@ def test_greedy_decode_tokens_match_reference_golden(golden, win):
     seq, probs = m.get_pred_seq_and_pred_prob_seq(x.to(DEV))
     assert seq == m.YHat[0]
     np.testing.assert_allclose(np.array(probs), g[f"w{win}_top1"], rtol=1e-3, atol=1e-4)
+    # KV-cached steps (default) and the reference-style full re-run give the same tokens and top-1 logits
+    seq_nc, probs_nc = m._greedy(m.encode(x.to(DEV)), want_probs=True, use_cache=False)
+    assert seq_nc == seq
+    np.testing.assert_allclose(np.array(probs_nc), np.array(probs), rtol=1e-4, atol=1e-5)
     m.Y.append(["a"])  # metric hook keys
     m.YHat.append(["a"])
     assert set(m.on_validation_epoch_end().keys()) == {"sym-er", "seq-er"}
@@ -275,3 +279,15 @@ def test_checkpoint_roundtrip(tmp_path):
     for (n1, a), (n2, b) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert n1 == n2 and torch.equal(a.cpu(), b.cpu())
     assert m2.config.d_model == 128
+
+
+def test_kv_cached_decode_matches_full_rerun_bf16_long():
+    """Longer sequence, attention window, bf16: cached and uncached greedy decoding agree token for token."""
+    V = 60
+    cfg = ModelConfig(d_model=128, ff_dim=128, num_layers=2, compute_dtype="bf16")
+    m, w2i = make_transformer(V, cfg, 9, hw=(32, 128), max_seq=40, win=7)
+    m.eval()
+    mem = m.encode(rnd((1, 1, 32, 128), 702).to(DEV))
+    a, _ = m._greedy(mem, use_cache=True)
+    b, _ = m._greedy(mem, use_cache=False)
+    assert a == b and len(a) >= 1
