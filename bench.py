@@ -130,6 +130,7 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         out["roofline"] = roofline_dominant_kernel(B, H, W, args.dtype)
+        out["decode"] = decode_rate(model, x[:1])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(H, W, T, V, args.layers)
     if rank == 0:
@@ -137,6 +138,28 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def decode_rate(model, x1, steps=96):
+    """Greedy decode rate (bs=1, KV cache, host argmax readback per token like model.py:187) on one benchmark image.
+    Random-init weights never emit <eos> reliably, so a fixed number of steps is timed."""
+    from omr_a2s_multimodal_transformer_amd import kernels as K
+    model.eval()
+    with torch.no_grad():
+        mem = model.encode(x1)
+        st = model.decoder.init_decode(mem)
+        tok = torch.full((1, 1), model.w2i["<sos>"], dtype=torch.int64, device=mem.device)
+        for i in range(steps + 8):
+            if i == 8:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            idx, _ = K.argmax(model.decoder.decode_step(tok, st).contiguous())
+            tok = idx.view(1, 1)
+            _ = int(idx.item())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    model.train()
+    return {"tokens_per_s": round(steps / dt, 1), "steps": steps, "memory_tokens": int(mem.shape[1]), "kv_cache": True}
 
 
 def roofline_dominant_kernel(B, H, W, dtype):
@@ -164,8 +187,15 @@ def roofline_dominant_kernel(B, H, W, dtype):
     nbytes = float(B) * H * W * (cin + cout) * x.element_size()
     flops = 2.0 * 9 * cin * cout * B * H * W
     gbs = nbytes / (ms * 1e-3) / 1e9
+    traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same launch (profiles/)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_dominant_kernel_pmc.json")) as f:
+            if (B, H, W, dtype) == (32, 256, 2048, "bf16"):
+                traffic = json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     return {"kernel": "conv3x3_mfma_kernel (conv_blocks.1.conv2: 32->32 ch @ full resolution)", "bound": "hbm",
-            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
             "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": nbytes,
             "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1), "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)}
 
