@@ -52,6 +52,9 @@ long omr_instnorm_workspace_bytes(int B, int C);
 /* nn.InstanceNorm2d(eps=1e-3, affine=False) statistics on x[B][HW][C] (encoder.py:151-156,174,232); the apply is
  * fused into the consumer conv (in_mean / in_rstd arguments below). */
 int omr_instnorm_stats(int dtype, const void* x, float* mean, float* rstd, int B, long HW, int C, float eps, void* workspace, void* stream);
+int omr_instnorm_finalize(const void* workspace, float* mean, float* rstd, int B, long HW, int C, float eps, void* stream);
+int omr_instnorm_bwd_apply(int dtype, const void* dxhat, const void* x, const float* mean, const float* rstd, void* dx, int B, long HW, int C,
+                           int relu_mask, float relu_scale, const void* workspace, void* stream);
 int omr_instnorm_bwd(int dtype, const void* dxhat, const void* x, const float* mean, const float* rstd, void* dx, int B, long HW, int C,
                      int relu_mask, float relu_scale, void* workspace, void* stream);
 /* post-norm residual: out = LayerNorm(x + res) (eps 1e-5), torch nn/modules/transformer.py:1146-1154 */
@@ -74,9 +77,15 @@ int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, int N, int K
  * (in_mean/in_rstd [B][CIN]) and optional epilogue mask (y = mask>0 ? y*mask_scale : 0).  Weights [COUT][3][3][CIN].
  * dil_* > 1 reads the input as if zero-dilated: with flipped weights (omr_conv3x3_weight_flip) this is the data
  * gradient of a strided conv.  CIN == 1 takes the direct (non-MFMA) first-layer path. */
+/* Fused on the output: MixDropout after the ReLU (drop_p > 0; encoder.py:165-179; elementwise mask keyed by the flat NHWC
+ * index, or per (image, channel) when drop_channel_mode) and a per-(image, channel) reduction over the stored tile into
+ * fp64 stat_ws[B][COUT][2] (zeroed by the caller): stat_mode 1 = {sum y, sum y^2} (InstanceNorm statistics of this
+ * output, finalised by omr_instnorm_finalize), stat_mode 2 = {sum g, sum g*xhat} with xhat = (stat_x - mean)*rstd
+ * (InstanceNorm backward sums when this call is the data gradient that produces g = dL/dxhat). */
 int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const float* bias, void* y, const float* in_mean, const float* in_rstd,
                     const void* out_mask, float mask_scale, int B, int H, int W, int CIN, int COUT, int stride_h, int stride_w, int dil_h,
-                    int dil_w, int Ho, int Wo, int relu, void* stream);
+                    int dil_w, int Ho, int Wo, int relu, float drop_p, unsigned long long drop_seed, int drop_channel_mode,
+                    int stat_mode, double* stat_ws, const void* stat_x, const float* stat_mean, const float* stat_rstd, void* stream);
 int omr_conv3x3_weight_flip(int dtype, const void* w, void* wd, int COUT, int CIN, void* stream);
 /* dw[COUT][3][3][CIN] (fp32) += dy^T * im2col(x);  db[COUT] (nullable, fp32) += column sums of dy (bias gradient) */
 int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, const float* in_mean, const float* in_rstd, int B, int H, int W,

@@ -15,282 +15,14 @@
 #include "omr_common.h"
 #include "omr_hip.h"
 
+#include "conv3x3_mfma.h"
+
+using omr_conv::ConvArgs;
+using omr_conv::TW;
+int omr_conv3x3_dispatch_bf16(const ConvArgs& a, hipStream_t s);
+int omr_conv3x3_dispatch_f32(const ConvArgs& a, hipStream_t s);
+
 namespace {
-
-constexpr int TW = 32;  // output tile width = one MFMA M-block (32 pixels of one output row)
-
-// Walk tile pixels pix = pix0 + k*DP (k = 0, 1, ...) keeping an incremental (row, col) inside a tile of width IW, in
-// batches of G: all G global loads are issued before the first LDS store so their latencies overlap (a plain
-// load->store loop serialises on s_waitcnt vmcnt(0) every iteration).
-template <int G, typename F, typename LoadFn, typename StoreFn>
-__device__ __forceinline__ void staged_walk(int pix0, int npix, int DP, int il0, int jl0, int di, int dj, int IW, LoadFn load, StoreFn store) {
-    int il = il0, jl = jl0;
-    for (int base = pix0; base < npix; base += G * DP) {
-        F v[G];
-        int pix = base;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if (pix < npix) v[g] = load(il, jl);
-            jl += dj; il += di;
-            if (jl >= IW) { jl -= IW; ++il; }
-            pix += DP;
-        }
-        pix = base;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if (pix < npix) store(pix, v[g]);
-            pix += DP;
-        }
-    }
-}
-
-struct ConvArgs {
-    const void* x; const void* w; const float* bias; void* y;
-    const float* mean; const float* rstd;        // [B][CIN] fused InstanceNorm apply on load (or null)
-    const void* mask; float mask_scale;          // epilogue: y = mask > 0 ? y * scale : 0   (ReLU/dropout backward of the consumer side)
-    int B, Hr, Wr, CIN, Ho, Wo, COUT;
-    int sh, sw, dh, dw, relu, tiles_w, tiles_h;
-};
-
-// ------------------------------------------------------------------------------------------------
-// 3x3 conv as implicit GEMM.  Block = 256 threads = 4 waves; output tile = (4*RPW) rows x 32 cols x NT couts.
-// Wave w owns tile rows [w*RPW, (w+1)*RPW) and all NT/32 cout blocks.  Blocks are PERSISTENT over output tiles
-// (grid-stride): when the whole reduction fits one channel chunk (CIN == CK: every 16/32-channel layer, i.e. all the
-// full-resolution ones) the weight tile is staged into LDS once per block instead of once per tile.
-// MFMA orientation: D[cout][pixel] (weights = A operand) so each lane owns one output pixel and its 16 accumulator
-// registers are 4 runs of 4 consecutive couts: bias/ReLU in registers, one 8-byte LDS store per run, then the tile
-// leaves LDS as 16-byte row-contiguous global stores (direct 8-byte global stores were measured 15 % slower).
-template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, bool SINGLE>
-__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
-    typedef typename Frag<T>::type F;
-    typedef __attribute__((ext_vector_type(4))) T T4;
-    constexpr int VEC = Frag<T>::N;
-    constexpr int CKP = CK + VEC;           // pitch (elements): 16-byte odd multiple -> conflict-free b128 reads
-    constexpr int NB = NT / 32;
-    constexpr int TH = 4 * RPW;
-    constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3, NPIX = IH * IW;
-    constexpr int CPP = CK / VEC;           // 16-byte chunks per pixel per channel chunk
-    constexpr int OP = NT + VEC;            // output staging pitch (elements)
-    // LDS: [Xs | Ws].  The output staging tile Os aliases Xs; when the weights are re-staged per chunk anyway (!SINGLE) it
-    // may also run over Ws, otherwise Xs is sized to hold it.
-    constexpr int XS_ELEMS = (SINGLE && TH * TW * OP > NPIX * CKP) ? TH * TW * OP : NPIX * CKP;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Xs = reinterpret_cast<T*>(smem_raw);
-    T* Os = Xs;
-    T* Ws = Xs + XS_ELEMS;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.y * NT;
-    const int Hv = (a.Hr - 1) * DH + 1, Wv = (a.Wr - 1) * DW + 1;
-    const T* W = (const T*)a.w;
-    constexpr bool single = SINGLE;   // the whole reduction is one channel chunk: weights staged once per block
-    const int frow = lane & 31, fk = (lane >> 5) * VEC, hsel = 4 * (lane >> 5);
-
-    auto stage_weights = [&](int c0) {      // Ws[n][tap][k] for channel chunk c0; one 16-byte chunk per thread per round
-        constexpr int NCH = NT * 9 * CPP, ROUNDS = (NCH + 255) / 256;
-        F v[ROUNDS];
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const int c = tid + r * 256, row = c / CPP, kc = (c % CPP) * VEC, n = n0 + row / 9;
-            v[r] = frag_zero<T>();
-            if (c < NCH && n < a.COUT) v[r] = *reinterpret_cast<const F*>(W + ((long)n * 9 + row % 9) * a.CIN + c0 + kc);
-        }
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const int c = tid + r * 256, row = c / CPP, kc = (c % CPP) * VEC;
-            if (c < NCH) *reinterpret_cast<F*>(Ws + (long)row * CKP + kc) = v[r];
-        }
-    };
-
-    // per-lane bias values for the 16 couts of each cout block (constant for the whole kernel)
-    float bv[NB][16];
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = n0 + j * 32 + (r & 3) + 8 * (r >> 2) + hsel;
-            bv[j][r] = (a.bias && n < a.COUT) ? a.bias[n] : 0.f;
-        }
-
-    if (single) stage_weights(0);
-
-    const int tiles_per_img = a.tiles_h * a.tiles_w, ntiles = a.B * tiles_per_img;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
-        const int th = rem / a.tiles_w, tw = rem - th * a.tiles_w;
-        const int oh0 = th * TH, ow0 = tw * TW;
-        const int vh0 = oh0 * SH - 1, vw0 = ow0 * SW - 1;           // virtual (dilated) input origin of the halo
-        const T* X = (const T*)a.x + (long)b * a.Hr * a.Wr * a.CIN;
-
-        f32x16 acc[RPW][NB];
-#pragma unroll
-        for (int i = 0; i < RPW; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-        for (int c0 = 0; c0 < a.CIN; c0 += CK) {
-            __syncthreads();                  // previous tile's store loop / previous chunk's MFMAs are done with Xs (and Ws)
-            // ---- stage the input halo: thread = one halo pixel per round (ONE bounds test + address for its CPP chunks:
-            //      measured 30 % faster than chunk-granular staging on the 16/32-channel layers, which are VALU-limited);
-            //      all loads of all rounds are issued before the first LDS store
-            {
-                constexpr int ROUNDS = (NPIX + 255) / 256;
-                F v[ROUNDS][CPP];
-#pragma unroll
-                for (int r = 0; r < ROUNDS; ++r) {
-                    const int pix = tid + r * 256;
-                    const int il = pix / IW, jl = pix - il * IW;
-                    const int vh = vh0 + il, vw = vw0 + jl;
-                    const bool ok = pix < NPIX && vh >= 0 && vh < Hv && vw >= 0 && vw < Wv && (vh & (DH - 1)) == 0 && (vw & (DW - 1)) == 0;
-                    const T* src = X + ((long)(vh >> (DH >> 1)) * a.Wr + (vw >> (DW >> 1))) * a.CIN + c0;
-#pragma unroll
-                    for (int k = 0; k < CPP; ++k) {
-                        v[r][k] = frag_zero<T>();
-                        if (ok) v[r][k] = *reinterpret_cast<const F*>(src + k * VEC);
-                    }
-                    if (ok && a.mean) {
-#pragma unroll
-                        for (int k = 0; k < CPP; ++k)
-#pragma unroll
-                            for (int e = 0; e < VEC; ++e) {
-                                const int ch = b * a.CIN + c0 + k * VEC + e;
-                                v[r][k][e] = from_f32<T>((to_f32(v[r][k][e]) - a.mean[ch]) * a.rstd[ch]);
-                            }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < ROUNDS; ++r) {
-                    const int pix = tid + r * 256;
-                    if (pix < NPIX)
-#pragma unroll
-                        for (int k = 0; k < CPP; ++k) *reinterpret_cast<F*>(Xs + (long)pix * CKP + k * VEC) = v[r][k];
-                }
-            }
-            if (!single) stage_weights(c0);
-            __syncthreads();
-            // ---- nine shifted GEMMs out of LDS
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int kh = tap / 3, kw = tap % 3;
-#pragma unroll
-                for (int kk = 0; kk < CK; kk += KStep<T>::value) {
-                    F af[RPW], bf[NB];
-#pragma unroll
-                    for (int i = 0; i < RPW; ++i) {
-                        const int pix = ((wave * RPW + i) * SH + kh) * IW + frow * SW + kw;
-                        af[i] = *reinterpret_cast<const F*>(Xs + (long)pix * CKP + kk + fk);
-                    }
-#pragma unroll
-                    for (int j = 0; j < NB; ++j)
-                        bf[j] = *reinterpret_cast<const F*>(Ws + (long)((j * 32 + frow) * 9 + tap) * CKP + kk + fk);
-#pragma unroll
-                    for (int i = 0; i < RPW; ++i)
-#pragma unroll
-                        for (int j = 0; j < NB; ++j) mma32(acc[i][j], bf[j], af[i]);   // D[cout][pixel]
-                }
-            }
-        }
-
-        // ---- epilogue
-        __syncthreads();                              // every wave is done reading Xs: Os aliases it
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                T* orow = Os + (long)((wave * RPW + i) * TW + frow) * OP + j * 32 + hsel;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    T4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[i][j][4 * g + e] + bv[j][4 * g + e];
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        o[e] = from_f32<T>(v);
-                    }
-                    *reinterpret_cast<T4*>(orow + 8 * g) = o;
-                }
-            }
-        __syncthreads();
-        T* Y = (T*)a.y + (long)b * a.Ho * a.Wo * a.COUT;
-        const T* Mk = a.mask ? (const T*)a.mask + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
-        constexpr int CPO = NT / VEC;
-#pragma unroll
-        for (int c = tid; c < TH * TW * CPO; c += 256) {
-            const int pl = c / CPO, kc = (c % CPO) * VEC;
-            const int oh = oh0 + pl / TW, ow = ow0 + pl % TW, n = n0 + kc;
-            if (oh >= a.Ho || ow >= a.Wo || n >= a.COUT) continue;
-            F v = *reinterpret_cast<const F*>(Os + (long)pl * OP + kc);
-            const long o = ((long)oh * a.Wo + ow) * a.COUT + n;
-            if (Mk) {
-                const F m = *reinterpret_cast<const F*>(Mk + o);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] = from_f32<T>(to_f32(m[e]) > 0.f ? to_f32(v[e]) * a.mask_scale : 0.f);
-            }
-            *reinterpret_cast<F*>(Y + o) = v;
-        }
-    }
-}
-
-template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, bool SINGLE> int launch_conv2(const ConvArgs& a0, hipStream_t s) {
-    ConvArgs a = a0;
-    constexpr int TH = 4 * RPW;
-    constexpr int CKP = CK + Frag<T>::N;
-    constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3, NPIX = IH * IW, OP = NT + Frag<T>::N;
-    constexpr int XS_ELEMS = (SINGLE && TH * TW * OP > NPIX * CKP) ? TH * TW * OP : NPIX * CKP;
-    a.tiles_w = cdiv(a.Wo, TW);
-    a.tiles_h = cdiv(a.Ho, TH);
-    size_t shm = ((size_t)XS_ELEMS + (size_t)NT * 9 * CKP) * sizeof(T);
-    if (!SINGLE && (size_t)TH * TW * OP * sizeof(T) > shm) shm = (size_t)TH * TW * OP * sizeof(T);
-    if (shm > 160 * 1024) return OMR_ERR_UNSUPPORTED;
-    if (a.COUT % Frag<T>::N) return OMR_ERR_UNSUPPORTED;
-    auto kern = conv3x3_mfma_kernel<T, NT, RPW, CK, SH, SW, DH, DW, SINGLE>;
-    if (shm > 48 * 1024) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return OMR_ERR_LAUNCH;
-    }
-    const int ny = cdiv(a.COUT, NT);
-    const long ntiles = (long)a.B * a.tiles_w * a.tiles_h;
-    long gx = 2048 / ny;                           // persistent: ~8 blocks per CU worth of slots, grid-stride over tiles
-    if (gx > ntiles) gx = ntiles;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, ny, 1), dim3(256), shm, s, a);
-    OMR_CHECK_LAUNCH();
-    return OMR_OK;
-}
-
-template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW> int launch_conv(const ConvArgs& a, hipStream_t s) {
-    if (a.CIN == CK) return launch_conv2<T, NT, RPW, CK, SH, SW, DH, DW, true>(a, s);
-    return launch_conv2<T, NT, RPW, CK, SH, SW, DH, DW, false>(a, s);
-}
-
-// stride / dilation combinations the encoder needs: forward (1,1) (2,2) (2,1); data gradient = stride 1 with dilation (2,2) / (2,1)
-template <typename T, int NT, int SH, int SW, int DH, int DW> int dispatch_conv_ck(const ConvArgs& a, hipStream_t s) {
-    constexpr int KS = KStep<T>::value;
-    constexpr bool strided = SH > 1 || SW > 1;
-    if (a.CIN % KS) return OMR_ERR_UNSUPPORTED;
-    if constexpr (strided) {
-        return launch_conv<T, NT, 1, KS, SH, SW, DH, DW>(a, s);
-    } else {
-        if (a.CIN % (2 * KS) == 0) return launch_conv<T, NT, 2, 2 * KS, SH, SW, DH, DW>(a, s);
-        return launch_conv<T, NT, 2, KS, SH, SW, DH, DW>(a, s);
-    }
-}
-template <typename T, int NT> int dispatch_conv_nt(const ConvArgs& a, hipStream_t s) {
-    if (a.dh == 1 && a.dw == 1) {
-        if (a.sh == 1 && a.sw == 1) return dispatch_conv_ck<T, NT, 1, 1, 1, 1>(a, s);
-        if (a.sh == 2 && a.sw == 2) return dispatch_conv_ck<T, NT, 2, 2, 1, 1>(a, s);
-        if (a.sh == 2 && a.sw == 1) return dispatch_conv_ck<T, NT, 2, 1, 1, 1>(a, s);
-        return OMR_ERR_UNSUPPORTED;
-    }
-    if (a.sh != 1 || a.sw != 1) return OMR_ERR_UNSUPPORTED;
-    if (a.dh == 2 && a.dw == 2) return dispatch_conv_ck<T, NT, 1, 1, 2, 2>(a, s);
-    if (a.dh == 2 && a.dw == 1) return dispatch_conv_ck<T, NT, 1, 1, 2, 1>(a, s);
-    return OMR_ERR_UNSUPPORTED;
-}
-template <typename T> int dispatch_conv(const ConvArgs& a, hipStream_t s) {
-    return a.COUT > 32 ? dispatch_conv_nt<T, 64>(a, s) : dispatch_conv_nt<T, 32>(a, s);
-}
 
 // ------------------------------------------------------------------------------------------------
 // Weight re-layout for the data gradient: Wd[c][8 - tap][n] = W[n][tap][c]   (transposed conv = conv with
@@ -748,12 +480,18 @@ inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g < 1 ? 1 : 
 
 extern "C" int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const float* bias, void* y, const float* in_mean, const float* in_rstd,
                                const void* out_mask, float mask_scale, int B, int H, int W, int CIN, int COUT, int stride_h, int stride_w,
-                               int dil_h, int dil_w, int Ho, int Wo, int relu, void* stream) {
+                               int dil_h, int dil_w, int Ho, int Wo, int relu, float drop_p, unsigned long long drop_seed,
+                               int drop_channel_mode, int stat_mode, double* stat_ws, const void* stat_x, const float* stat_mean,
+                               const float* stat_rstd, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0 || CIN <= 0 || COUT <= 0 || !x || !w || !y) return OMR_ERR_ARG;
     if (stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1 || dil_h > 2 || dil_w > 2) return OMR_ERR_ARG;
     if ((stride_h > 1 || stride_w > 1) && (dil_h > 1 || dil_w > 1)) return OMR_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    if (drop_p < 0.f || drop_p >= 1.f || stat_mode < 0 || stat_mode > 2) return OMR_ERR_ARG;
+    if (stat_mode && !stat_ws) return OMR_ERR_ARG;
+    if (stat_mode == 2 && (!stat_x || !stat_mean || !stat_rstd)) return OMR_ERR_ARG;
     if (CIN == 1) {
+        if (drop_p > 0.f || stat_mode) return OMR_ERR_UNSUPPORTED;
         if (dil_h != 1 || dil_w != 1 || stride_h != 1 || stride_w != 1 || in_mean || out_mask || Ho != H || Wo != W) return OMR_ERR_UNSUPPORTED;
         int gy1 = B * H; if (gy1 > 1024) gy1 = 1024;
         dim3 g1(cdiv(W, 256), gy1);
@@ -769,7 +507,12 @@ extern "C" int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const fl
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.mean = in_mean; a.rstd = in_rstd; a.mask = out_mask; a.mask_scale = mask_scale;
     a.B = B; a.Hr = H; a.Wr = W; a.CIN = CIN; a.Ho = Ho; a.Wo = Wo; a.COUT = COUT;
     a.sh = stride_h; a.sw = stride_w; a.dh = dil_h; a.dw = dil_w; a.relu = relu; a.tiles_w = a.tiles_h = 0;
-    DISPATCH_T(dtype, return dispatch_conv<T>(a, s));
+    a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_scale = 1.f / (1.f - drop_p); a.drop_seed = drop_seed;
+    a.drop_channel = drop_channel_mode;
+    a.stat_mode = stat_mode; a.stat_ws = stat_ws; a.stat_x = stat_x; a.stat_mean = stat_mean; a.stat_rstd = stat_rstd;
+    if (dtype == OMR_BF16) return omr_conv3x3_dispatch_bf16(a, s);
+    if (dtype == OMR_F32) return omr_conv3x3_dispatch_f32(a, s);
+    return OMR_ERR_UNSUPPORTED;
 }
 
 extern "C" int omr_conv3x3_weight_flip(int dtype, const void* w, void* wd, int COUT, int CIN, void* stream) {

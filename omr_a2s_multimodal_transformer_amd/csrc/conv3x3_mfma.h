@@ -1,0 +1,379 @@
+// conv3x3 implicit-GEMM kernel (forward and data gradient) -- shared by conv_bf16.hip / conv_f32.hip so the two dtypes
+// compile in parallel.  See conv.hip for the overview.
+#pragma once
+#include <type_traits>
+
+#include "omr_common.h"
+
+namespace omr_conv {
+
+constexpr int TW = 32;  // output tile width = one MFMA M-block (32 pixels of one output row)
+
+// Walk tile pixels pix = pix0 + k*DP (k = 0, 1, ...) keeping an incremental (row, col) inside a tile of width IW, in
+// batches of G: all G global loads are issued before the first LDS store so their latencies overlap (a plain
+// load->store loop serialises on s_waitcnt vmcnt(0) every iteration).
+template <int G, typename F, typename LoadFn, typename StoreFn>
+__device__ __forceinline__ void staged_walk(int pix0, int npix, int DP, int il0, int jl0, int di, int dj, int IW, LoadFn load, StoreFn store) {
+    int il = il0, jl = jl0;
+    for (int base = pix0; base < npix; base += G * DP) {
+        F v[G];
+        int pix = base;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (pix < npix) v[g] = load(il, jl);
+            jl += dj; il += di;
+            if (jl >= IW) { jl -= IW; ++il; }
+            pix += DP;
+        }
+        pix = base;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (pix < npix) store(pix, v[g]);
+            pix += DP;
+        }
+    }
+}
+
+struct ConvArgs {
+    const void* x; const void* w; const float* bias; void* y;
+    const float* mean; const float* rstd;        // [B][CIN] fused InstanceNorm apply on load (or null)
+    const void* mask; float mask_scale;          // epilogue: y = mask > 0 ? y * scale : 0   (ReLU/dropout backward of the consumer side)
+    int B, Hr, Wr, CIN, Ho, Wo, COUT;
+    int sh, sw, dh, dw, relu, tiles_w, tiles_h;
+    // fused dropout on the output (after ReLU): counter-based mask keyed by the flat NHWC index (or (b, channel))
+    uint32_t drop_thresh; float drop_scale; uint64_t drop_seed; int drop_channel;
+    // fused per-(image, channel) reductions over the STORED output tile (fp64 accumulators stat_ws[B][COUT][2]):
+    //   mode 1: {sum y, sum y^2}            -> InstanceNorm statistics of this conv's output (encoder.py:174)
+    //   mode 2: {sum g, sum g * xhat}       -> InstanceNorm backward sums, xhat = (stat_x - mean) * rstd at the same position
+    int stat_mode; double* stat_ws; const void* stat_x; const float* stat_mean; const float* stat_rstd;
+};
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 conv as implicit GEMM.  Block = 256 threads = 4 waves; output tile = (4*RPW) rows x 32 cols x NT couts.
+// Wave w owns tile rows [w*RPW, (w+1)*RPW) and all NT/32 cout blocks.  Blocks are PERSISTENT over output tiles
+// (grid-stride): when the whole reduction fits one channel chunk (CIN == CK: every 16/32-channel layer, i.e. all the
+// full-resolution ones) the weight tile is staged into LDS once per block instead of once per tile.
+// MFMA orientation: D[cout][pixel] (weights = A operand) so each lane owns one output pixel and its 16 accumulator
+// registers are 4 runs of 4 consecutive couts: bias/ReLU in registers, one 8-byte LDS store per run, then the tile
+// leaves LDS as 16-byte row-contiguous global stores (direct 8-byte global stores were measured 15 % slower).
+// EPI selects the fused-epilogue code that is compiled in (keeps the plain kernel's register footprint small):
+//   0 plain | 1 forward extras: MixDropout + InstanceNorm statistics of the output | 2 backward extras: InstanceNorm-backward sums
+template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, bool SINGLE, int EPI>
+__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
+    typedef typename Frag<T>::type F;
+    typedef __attribute__((ext_vector_type(4))) T T4;
+    constexpr int VEC = Frag<T>::N;
+    constexpr int CKP = CK + VEC;           // pitch (elements): 16-byte odd multiple -> conflict-free b128 reads
+    constexpr int NB = NT / 32;
+    constexpr int TH = 4 * RPW;
+    constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3, NPIX = IH * IW;
+    constexpr int CPP = CK / VEC;           // 16-byte chunks per pixel per channel chunk
+    constexpr int OP = NT + VEC;            // output staging pitch (elements)
+    // LDS: [Xs | Ws].  The output staging tile Os aliases Xs; when the weights are re-staged per chunk anyway (!SINGLE) it
+    // may also run over Ws, otherwise Xs is sized to hold it.
+    constexpr int XS_ELEMS = (SINGLE && TH * TW * OP > NPIX * CKP) ? TH * TW * OP : NPIX * CKP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Xs = reinterpret_cast<T*>(smem_raw);
+    T* Os = Xs;
+    T* Ws = Xs + XS_ELEMS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.y * NT;
+    const int Hv = (a.Hr - 1) * DH + 1, Wv = (a.Wr - 1) * DW + 1;
+    const T* W = (const T*)a.w;
+    constexpr bool single = SINGLE;   // the whole reduction is one channel chunk: weights staged once per block
+    const int frow = lane & 31, fk = (lane >> 5) * VEC, hsel = 4 * (lane >> 5);
+
+    auto stage_weights = [&](int c0) {      // Ws[n][tap][k] for channel chunk c0; 16-byte chunks, loads batched four at a time
+        constexpr int NCH = NT * 9 * CPP, ROUNDS = (NCH + 255) / 256, GB = 4;
+#pragma unroll
+        for (int r0 = 0; r0 < ROUNDS; r0 += GB) {
+            F v[GB];
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+                const int c = tid + (r0 + g) * 256, row = c / CPP, kc = (c % CPP) * VEC, n = n0 + row / 9;
+                v[g] = frag_zero<T>();
+                if (r0 + g < ROUNDS && c < NCH && n < a.COUT) v[g] = *reinterpret_cast<const F*>(W + ((long)n * 9 + row % 9) * a.CIN + c0 + kc);
+            }
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+                const int c = tid + (r0 + g) * 256, row = c / CPP, kc = (c % CPP) * VEC;
+                if (r0 + g < ROUNDS && c < NCH) *reinterpret_cast<F*>(Ws + (long)row * CKP + kc) = v[g];
+            }
+        }
+    };
+
+    __shared__ __attribute__((aligned(16))) float sbias[NT];     // bias of this block's couts (read back as float4 runs)
+    for (int i = tid; i < NT; i += 256) sbias[i] = (a.bias && n0 + i < a.COUT) ? a.bias[n0 + i] : 0.f;
+
+    if (single) stage_weights(0);
+
+    // fused reductions: this thread always stores the same VEC-channel chunk, so it keeps fp32 partials in registers and the
+    // block flushes them (LDS -> one fp64 atomic per channel) only when its tile range moves on to another image
+    __shared__ float sred[EPI ? 2 * NT : 4];
+    constexpr int CPO = NT / VEC;
+    constexpr int NSV = EPI ? VEC : 1;
+    float ssum[NSV], ssq[NSV], smu[NSV], srs[NSV];
+#pragma unroll
+    for (int e = 0; e < NSV; ++e) { ssum[e] = ssq[e] = 0.f; smu[e] = 0.f; srs[e] = 1.f; }
+    const bool stat1 = EPI == 1 && a.stat_mode == 1, stat2 = EPI == 2 && a.stat_mode == 2;
+    auto flush_stats = [&](int bimg) {
+        if constexpr (EPI == 0) return;
+        for (int i = tid; i < 2 * NT; i += 256) sred[i] = 0.f;
+        __syncthreads();
+        const int kcs = (tid % CPO) * VEC;
+#pragma unroll
+        for (int e = 0; e < NSV; ++e) {
+            atomicAdd(&sred[(kcs + e) * 2], ssum[e]);
+            atomicAdd(&sred[(kcs + e) * 2 + 1], ssq[e]);
+            ssum[e] = ssq[e] = 0.f;
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * NT; i += 256) {
+            const int n = n0 + (i >> 1);
+            if (n < a.COUT) atomicAdd(&a.stat_ws[((long)bimg * a.COUT + n) * 2 + (i & 1)], (double)sred[i]);
+        }
+        __syncthreads();
+    };
+
+    // persistent schedule: blockIdx.z = image; the gridDim.x blocks of an image walk its tiles with stride gridDim.x, so
+    // concurrently running blocks work on adjacent tiles (halo rows shared through L2) and a block only ever sees ONE image
+    // (its fused-reduction partials are flushed once, at the end)
+    const int tiles_per_img = a.tiles_h * a.tiles_w;
+    const int b = blockIdx.z;
+    if (stat2) {
+#pragma unroll
+        for (int e = 0; e < NSV; ++e) {
+            const int n = n0 + (tid % CPO) * VEC + e;
+            smu[e] = n < a.COUT ? a.stat_mean[(long)b * a.COUT + n] : 0.f;
+            srs[e] = n < a.COUT ? a.stat_rstd[(long)b * a.COUT + n] : 1.f;
+        }
+    }
+    for (int rem = blockIdx.x; rem < tiles_per_img; rem += gridDim.x) {
+        const int th = rem / a.tiles_w, tw = rem - th * a.tiles_w;
+        const int oh0 = th * TH, ow0 = tw * TW;
+        const int vh0 = oh0 * SH - 1, vw0 = ow0 * SW - 1;           // virtual (dilated) input origin of the halo
+        const T* X = (const T*)a.x + (long)b * a.Hr * a.Wr * a.CIN;
+
+        f32x16 acc[RPW][NB];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int c0 = 0; c0 < a.CIN; c0 += CK) {
+            __syncthreads();                  // previous tile's store loop / previous chunk's MFMAs are done with Xs (and Ws)
+            // ---- stage the input halo: thread = one halo pixel per round (ONE bounds test + address for its CPP chunks:
+            //      measured 30 % faster than chunk-granular staging on the 16/32-channel layers, which are VALU-limited);
+            //      all loads of all rounds are issued before the first LDS store
+            {
+                constexpr int ROUNDS = (NPIX + 255) / 256;
+                F v[ROUNDS][CPP];
+#pragma unroll
+                for (int r = 0; r < ROUNDS; ++r) {
+                    const int pix = tid + r * 256;
+                    const int il = pix / IW, jl = pix - il * IW;
+                    const int vh = vh0 + il, vw = vw0 + jl;
+                    const bool ok = pix < NPIX && vh >= 0 && vh < Hv && vw >= 0 && vw < Wv && (vh & (DH - 1)) == 0 && (vw & (DW - 1)) == 0;
+                    const T* src = X + ((long)(vh >> (DH >> 1)) * a.Wr + (vw >> (DW >> 1))) * a.CIN + c0;
+#pragma unroll
+                    for (int k = 0; k < CPP; ++k) {
+                        v[r][k] = frag_zero<T>();
+                        if (ok) v[r][k] = *reinterpret_cast<const F*>(src + k * VEC);
+                    }
+                    if (ok && a.mean) {
+#pragma unroll
+                        for (int k = 0; k < CPP; ++k)
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) {
+                                const int ch = b * a.CIN + c0 + k * VEC + e;
+                                v[r][k][e] = from_f32<T>((to_f32(v[r][k][e]) - a.mean[ch]) * a.rstd[ch]);
+                            }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < ROUNDS; ++r) {
+                    const int pix = tid + r * 256;
+                    if (pix < NPIX)
+#pragma unroll
+                        for (int k = 0; k < CPP; ++k) *reinterpret_cast<F*>(Xs + (long)pix * CKP + k * VEC) = v[r][k];
+                }
+            }
+            if (!single) stage_weights(c0);
+            __syncthreads();
+            // ---- nine shifted GEMMs out of LDS
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+                for (int kk = 0; kk < CK; kk += KStep<T>::value) {
+                    F af[RPW], bf[NB];
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i) {
+                        const int pix = ((wave * RPW + i) * SH + kh) * IW + frow * SW + kw;
+                        af[i] = *reinterpret_cast<const F*>(Xs + (long)pix * CKP + kk + fk);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        bf[j] = *reinterpret_cast<const F*>(Ws + (long)((j * 32 + frow) * 9 + tap) * CKP + kk + fk);
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) mma32(acc[i][j], bf[j], af[i]);   // D[cout][pixel]
+                }
+            }
+        }
+
+        // ---- epilogue
+        __syncthreads();                              // every wave is done reading Xs: Os aliases it
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                T* orow = Os + (long)((wave * RPW + i) * TW + frow) * OP + j * 32 + hsel;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    T4 o;
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(&sbias[j * 32 + 8 * g + hsel]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][4 * g + e] + bq[e];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        o[e] = from_f32<T>(v);
+                    }
+                    *reinterpret_cast<T4*>(orow + 8 * g) = o;
+                }
+            }
+        __syncthreads();
+        T* Y = (T*)a.y + (long)b * a.Ho * a.Wo * a.COUT;
+        const T* Mk = a.mask ? (const T*)a.mask + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
+        const T* SX = stat2 ? (const T*)a.stat_x + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
+        const uint64_t img_base = (uint64_t)b * a.Ho * a.Wo * a.COUT;
+#pragma unroll(EPI == 0 ? 8 : 1)
+        for (int c = tid; c < TH * TW * CPO; c += 256) {
+            const int pl = c / CPO, kc = (c % CPO) * VEC;
+            const int oh = oh0 + pl / TW, ow = ow0 + pl % TW, n = n0 + kc;
+            if (oh >= a.Ho || ow >= a.Wo || n >= a.COUT) continue;
+            F v = *reinterpret_cast<const F*>(Os + (long)pl * OP + kc);
+            const long o = ((long)oh * a.Wo + ow) * a.COUT + n;
+            if constexpr (EPI == 1) {
+                if (a.drop_thresh) {   // MixDropout after the ReLU, keyed exactly like omr_dropout (flat NHWC index / (image, channel))
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const uint64_t idx = a.drop_channel ? (uint64_t)b * a.COUT + n + e : img_base + (uint64_t)o + e;
+                        v[e] = drop_keep(a.drop_seed, idx, a.drop_thresh) ? from_f32<T>(to_f32(v[e]) * a.drop_scale) : from_f32<T>(0.f);
+                    }
+                }
+            }
+            if (Mk) {
+                const F m = *reinterpret_cast<const F*>(Mk + o);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = from_f32<T>(to_f32(m[e]) > 0.f ? to_f32(v[e]) * a.mask_scale : 0.f);
+            }
+            *reinterpret_cast<F*>(Y + o) = v;
+            if constexpr (EPI == 1) {
+                if (stat1) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { const float f = to_f32(v[e]); ssum[e] += f; ssq[e] += f * f; }
+                }
+            } else if constexpr (EPI == 2) {
+                if (stat2) {
+                    const F xv = *reinterpret_cast<const F*>(SX + o);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { const float f = to_f32(v[e]); ssum[e] += f; ssq[e] += f * ((to_f32(xv[e]) - smu[e]) * srs[e]); }
+                }
+            }
+        }
+    }
+    if (stat1 || stat2) flush_stats(b);
+}
+
+template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, bool SINGLE, int EPI> int launch_conv3(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    constexpr int TH = 4 * RPW;
+    constexpr int CKP = CK + Frag<T>::N;
+    constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3, NPIX = IH * IW, OP = NT + Frag<T>::N;
+    constexpr int XS_ELEMS = (SINGLE && TH * TW * OP > NPIX * CKP) ? TH * TW * OP : NPIX * CKP;
+    a.tiles_w = cdiv(a.Wo, TW);
+    a.tiles_h = cdiv(a.Ho, TH);
+    size_t shm = ((size_t)XS_ELEMS + (size_t)NT * 9 * CKP) * sizeof(T);
+    if (!SINGLE && (size_t)TH * TW * OP * sizeof(T) > shm) shm = (size_t)TH * TW * OP * sizeof(T);
+    if (shm > 160 * 1024) return OMR_ERR_UNSUPPORTED;
+    if (a.COUT % Frag<T>::N) return OMR_ERR_UNSUPPORTED;
+    auto kern = conv3x3_mfma_kernel<T, NT, RPW, CK, SH, SW, DH, DW, SINGLE, EPI>;
+    if (shm > 48 * 1024) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return OMR_ERR_LAUNCH;
+    }
+    const int ny = cdiv(a.COUT, NT);
+    const long tiles_per_img = (long)a.tiles_w * a.tiles_h;
+    // persistent grid = the block slots the chip really has for this kernel (256 CUs x resident blocks per CU), split
+    // evenly over the images: every block is resident from the start, no tail of queued blocks
+    static int occ_cache = 0;
+    if (occ_cache == 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, shm) != hipSuccess || occ < 1) occ = 2;
+        occ_cache = occ;
+    }
+    long gx = (256L * occ_cache + (long)ny * a.B - 1) / ((long)ny * a.B);
+    if (gx > tiles_per_img) gx = tiles_per_img;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, ny, a.B), dim3(256), shm, s, a);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+// Which epilogue variants exist: forward extras (1) only without dilation, backward extras (2) only with unit stride; the
+// fp32 (parity) build has no plain variant at all (it takes 1 or 2 with the features switched off at run time).
+template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, bool SINGLE> int launch_conv2(const ConvArgs& a, hipStream_t s) {
+    constexpr bool can1 = (DH == 1 && DW == 1), can2 = (SH == 1 && SW == 1);
+    constexpr bool is_f32 = std::is_same<T, float>::value;
+    int epi = (a.stat_mode == 2) ? 2 : ((a.drop_thresh || a.stat_mode == 1) ? 1 : 0);
+    if (is_f32 && epi == 0) epi = can1 ? 1 : 2;
+    if (epi == 1) {
+        if constexpr (can1) return launch_conv3<T, NT, RPW, CK, SH, SW, DH, DW, SINGLE, 1>(a, s);
+        else return OMR_ERR_UNSUPPORTED;
+    }
+    if (epi == 2) {
+        if constexpr (can2) return launch_conv3<T, NT, RPW, CK, SH, SW, DH, DW, SINGLE, 2>(a, s);
+        else return OMR_ERR_UNSUPPORTED;
+    }
+    if constexpr (!is_f32) return launch_conv3<T, NT, RPW, CK, SH, SW, DH, DW, SINGLE, 0>(a, s);
+    else return OMR_ERR_UNSUPPORTED;
+}
+template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW> int launch_conv(const ConvArgs& a, hipStream_t s) {
+    if (a.CIN == CK) return launch_conv2<T, NT, RPW, CK, SH, SW, DH, DW, true>(a, s);
+    return launch_conv2<T, NT, RPW, CK, SH, SW, DH, DW, false>(a, s);
+}
+
+// stride / dilation combinations the encoder needs: forward (1,1) (2,2) (2,1); data gradient = stride 1 with dilation (2,2) / (2,1)
+template <typename T, int NT, int SH, int SW, int DH, int DW> int dispatch_conv_ck(const ConvArgs& a, hipStream_t s) {
+    constexpr int KS = KStep<T>::value;
+    constexpr bool strided = SH > 1 || SW > 1;
+    if (a.CIN % KS) return OMR_ERR_UNSUPPORTED;
+    if constexpr (strided) {
+        return launch_conv<T, NT, 1, KS, SH, SW, DH, DW>(a, s);
+    } else {
+        if (a.CIN % (2 * KS) == 0) return launch_conv<T, NT, 2, 2 * KS, SH, SW, DH, DW>(a, s);
+        return launch_conv<T, NT, 2, KS, SH, SW, DH, DW>(a, s);
+    }
+}
+template <typename T, int NT> int dispatch_conv_nt(const ConvArgs& a, hipStream_t s) {
+    if (a.dh == 1 && a.dw == 1) {
+        if (a.sh == 1 && a.sw == 1) return dispatch_conv_ck<T, NT, 1, 1, 1, 1>(a, s);
+        if (a.sh == 2 && a.sw == 2) return dispatch_conv_ck<T, NT, 2, 2, 1, 1>(a, s);
+        if (a.sh == 2 && a.sw == 1) return dispatch_conv_ck<T, NT, 2, 1, 1, 1>(a, s);
+        return OMR_ERR_UNSUPPORTED;
+    }
+    if (a.sh != 1 || a.sw != 1) return OMR_ERR_UNSUPPORTED;
+    if (a.dh == 2 && a.dw == 2) return dispatch_conv_ck<T, NT, 1, 1, 2, 2>(a, s);
+    if (a.dh == 2 && a.dw == 1) return dispatch_conv_ck<T, NT, 1, 1, 2, 1>(a, s);
+    return OMR_ERR_UNSUPPORTED;
+}
+template <typename T> int dispatch_conv(const ConvArgs& a, hipStream_t s) {
+    return a.COUT > 32 ? dispatch_conv_nt<T, 64>(a, s) : dispatch_conv_nt<T, 32>(a, s);
+}
+
+
+}  // namespace omr_conv

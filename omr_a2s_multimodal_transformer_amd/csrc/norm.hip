@@ -235,6 +235,30 @@ extern "C" int omr_instnorm_stats(int dtype, const void* x, float* mean, float* 
     return OMR_OK;
 }
 
+/* mean / rstd from fp64 {sum, sum of squares} accumulators that a producer kernel filled (omr_conv3x3_fwd stat_mode 1) */
+extern "C" int omr_instnorm_finalize(const void* workspace, float* mean, float* rstd, int B, long HW, int C, float eps, void* stream) {
+    if (B <= 0 || HW <= 0 || C <= 0 || !workspace) return OMR_ERR_ARG;
+    long n = (long)B * C;
+    hipLaunchKernelGGL(instnorm_finalize_kernel, cdiv(n, 256), 256, 0, (hipStream_t)stream, (const double*)workspace, mean, rstd, n, 1.0 / (double)HW, eps);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+/* apply step of the InstanceNorm backward with {sum g, sum g*xhat} already accumulated in `workspace`
+ * (omr_conv3x3_fwd stat_mode 2 fuses that reduction into the data-gradient conv that produces dxhat) */
+extern "C" int omr_instnorm_bwd_apply(int dtype, const void* dxhat, const void* x, const float* mean, const float* rstd, void* dx, int B, long HW,
+                                      int C, int relu_mask, float relu_scale, const void* workspace, void* stream) {
+    if (B <= 0 || HW <= 0 || C <= 0 || !workspace) return OMR_ERR_ARG;
+    const int vec = dtype == OMR_BF16 ? 8 : 4;
+    if (C % vec || 256 % (C / vec)) return OMR_ERR_UNSUPPORTED;
+    int ppb2 = 1024;
+    dim3 grid2(cdiv(HW, ppb2), B);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), grid2, 256, 0, (hipStream_t)stream, (const T*)dxhat, (const T*)x, mean, rstd,
+                                         (const double*)workspace, (T*)dx, HW, C, ppb2, (float)(1.0 / (double)HW), relu_mask, relu_scale));
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
 extern "C" int omr_instnorm_bwd(int dtype, const void* dxhat, const void* x, const float* mean, const float* rstd, void* dx, int B, long HW,
                                 int C, int relu_mask, float relu_scale, void* workspace, void* stream) {
     if (B <= 0 || HW <= 0 || C <= 0 || !workspace) return OMR_ERR_ARG;

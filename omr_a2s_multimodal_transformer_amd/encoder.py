@@ -97,25 +97,36 @@ class ConvBlock(nn.Module):
         self.conv3 = Conv2d(out_c, out_c, (3, 3), padding=(1, 1), stride=self.stride)
         self.dropout = MixDropout(dropout_prob=dropout, dropout_2d_prob=dropout / 2)
 
+    def _drop(self):
+        """MixDropout choice for the conv kernel's fused epilogue: (p, seed, channel_mode) or None (eval / p = 0).
+        Consumes one `random.random()` like MixDropout.forward (encoder.py:102), in eval mode too."""
+        p, channel_mode = self.dropout.pick()
+        if not self.training or p <= 0.0:
+            return None
+        return (p, next_seed(), channel_mode)
+
     def nhwc(self, x: torch.Tensor, in_mask: bool, in_scale: float, defer_out: bool) -> Tuple[torch.Tensor, float]:
         """x NHWC.  in_mask/in_scale: x is a ReLU(+dropout) output whose activation backward this block must
         apply.  defer_out: the consumer of the returned tensor applies OUR final ReLU(+dropout) backward;
-        returns (y, scale) with scale = 1/(1-p) of a dropout applied after conv3 (else 1)."""
+        returns (y, scale) with scale = 1/(1-p) of a dropout applied after conv3 (else 1).
+        Every conv is ONE kernel: bias, ReLU, the MixDropout of this position, the InstanceNorm statistics (conv2) and
+        the InstanceNorm apply (conv3's loads) are fused into it."""
         pos = random.randint(1, 3)  # encoder.py:160 (drawn in eval mode too)
         c1, c2, c3 = self.conv1, self.conv2, self.conv3
-        x = Fn.Conv3x3Fn.apply(x, c1.weight, c1.bias, (1, 1), True, False, False, in_mask, in_scale)
-        s = 1.0
-        if pos == 1:
-            x, s = self.dropout.apply_nhwc(x, True)
-        x = Fn.Conv3x3Fn.apply(x, c2.weight, c2.bias, (1, 1), True, False, False, True, s)
-        s = 1.0
-        if pos == 2:
-            x, s = self.dropout.apply_nhwc(x, True)
-        x = Fn.Conv3x3Fn.apply(x, c3.weight, c3.bias, self.stride, True, True, not defer_out, True, s)
-        s = 1.0
-        if pos == 3:
-            x, s = self.dropout.apply_nhwc(x, defer_out)
-        return x, s
+        d1 = self._drop() if pos == 1 else None
+        if d1 is not None and x.shape[-1] == 1:      # 1-channel first layer: direct kernel without the fused dropout
+            x = Fn.Conv3x3Fn.apply(x, c1.weight, c1.bias, (1, 1), True, None, False, in_mask, in_scale, None, False)
+            x = Fn.DropoutFn.apply(x, d1[0], d1[1], d1[2], True)
+        else:
+            x = Fn.Conv3x3Fn.apply(x, c1.weight, c1.bias, (1, 1), True, None, False, in_mask, in_scale, d1, False)
+        s1 = 1.0 / (1.0 - d1[0]) if d1 is not None else 1.0
+        d2 = self._drop() if pos == 2 else None
+        x, mean, rstd = Fn.Conv3x3Fn.apply(x, c2.weight, c2.bias, (1, 1), True, None, False, True, s1, d2, True)
+        s2 = 1.0 / (1.0 - d2[0]) if d2 is not None else 1.0
+        d3 = self._drop() if pos == 3 else None
+        x = Fn.Conv3x3Fn.apply(x, c3.weight, c3.bias, self.stride, True, (mean, rstd), not defer_out, True, s2, d3, False)
+        s3 = 1.0 / (1.0 - d3[0]) if d3 is not None else 1.0
+        return x, s3
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y, _ = self.nhwc(_to_nhwc(x), False, 1.0, False)

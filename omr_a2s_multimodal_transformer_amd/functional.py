@@ -40,26 +40,39 @@ def split_k_for(m_red: int) -> int:
 # ------------------------------------------------------------------------------------------------ encoder
 
 class Conv3x3Fn(Function):
-    """[InstanceNorm ->] Conv2d(3x3, pad 1, stride) -> +bias [-> ReLU] on NHWC  (ConvBlock, encoder.py:159-181)."""
+    """[InstanceNorm-apply ->] Conv2d(3x3, pad 1, stride) -> +bias [-> ReLU] [-> MixDropout] on NHWC, one kernel
+    (ConvBlock, encoder.py:159-181).  in_stats = (mean, rstd) of the input (fused normalisation on load).
+    drop = (p, seed, channel_mode) fuses the dropout into the epilogue; want_stats additionally returns the
+    InstanceNorm statistics of the (dropped) output, reduced inside the same kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, relu, use_norm, mask_own, mask_input, in_scale):
+    def forward(ctx, x, weight, bias, stride, relu, in_stats, mask_own, mask_input, in_scale, drop, want_stats):
         dt = x.dtype
-        stats = K.instnorm_stats(x) if use_norm else None
-        y = K.conv3x3(x, wt(weight, dt), bias.omr_phys, stride=stride, relu=relu, in_stats=stats)
-        ctx.cfg = (stride, relu, mask_own, mask_input, in_scale)
-        ctx.weight, ctx.bias, ctx.stats = weight, bias, stats
+        B = x.shape[0]
+        cout = weight.shape[0]
+        if drop is not None and x.shape[-1] == 1:
+            raise RuntimeError("fused dropout is not available on the 1-channel first-layer kernel")
+        ws = torch.zeros((B, cout, 2), dtype=torch.float64, device=x.device) if want_stats else None
+        y = K.conv3x3(x, wt(weight, dt), bias.omr_phys, stride=stride, relu=relu, in_stats=in_stats, drop=drop,
+                      stat_mode=1 if want_stats else 0, stat_ws=ws)
+        own_scale = 1.0 / (1.0 - drop[0]) if drop is not None else 1.0
+        ctx.cfg = (stride, relu, mask_own, mask_input, in_scale, own_scale)
+        ctx.weight, ctx.bias, ctx.stats = weight, bias, in_stats
         ctx.save_for_backward(x, y if (relu and mask_own) else None)
+        if want_stats:
+            mean, rstd = K.instnorm_finalize(ws, y.shape[1] * y.shape[2])
+            ctx.mark_non_differentiable(mean, rstd)
+            return y, mean, rstd
         return y
 
     @staticmethod
-    def backward(ctx, gy):
-        stride, relu, mask_own, mask_input, in_scale = ctx.cfg
+    def backward(ctx, gy, *unused):
+        stride, relu, mask_own, mask_input, in_scale, own_scale = ctx.cfg
         x, y = ctx.saved_tensors
         weight, bias, stats = ctx.weight, ctx.bias, ctx.stats
         g = gy.contiguous()
         if relu and mask_own:
-            g = K.relu_bwd(g, y)
+            g = K.relu_bwd(g, y, own_scale)        # y is the stored (dropped) output: (y > 0) * 1/(1-p) is ReLU + dropout backward
         K.conv3x3_wgrad(x, g, weight.omr_grad, stride=stride, in_stats=stats, db=bias.omr_grad)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -68,9 +81,11 @@ class Conv3x3Fn(Function):
             if stats is None:
                 dx = K.conv3x3(g, wd, None, stride=(1, 1), dil=stride, out_hw=(H, W), out_mask=x if mask_input else None, mask_scale=in_scale)
             else:
-                dxh = K.conv3x3(g, wd, None, stride=(1, 1), dil=stride, out_hw=(H, W))
-                dx = K.instnorm_bwd(dxh, x, stats[0], stats[1], relu_mask=mask_input, relu_scale=in_scale)
-        return dx, None, None, None, None, None, None, None, None
+                # data gradient w.r.t. the normalised input, with the InstanceNorm-backward sums reduced in its epilogue
+                ws = torch.zeros((x.shape[0], x.shape[3], 2), dtype=torch.float64, device=x.device)
+                dxh = K.conv3x3(g, wd, None, stride=(1, 1), dil=stride, out_hw=(H, W), stat_mode=2, stat_ws=ws, stat_x=x, stat_stats=stats)
+                dx = K.instnorm_bwd_apply(dxh, x, stats[0], stats[1], ws, relu_mask=mask_input, relu_scale=in_scale)
+        return (dx,) + (None,) * 10
 
 
 class DwConv3x3Fn(Function):

@@ -159,6 +159,27 @@ def instnorm_stats(x: Tensor, eps: float = 1e-3) -> Tuple[Tensor, Tensor]:
     return mean, rstd
 
 
+def instnorm_finalize(ws: Tensor, HW: int, eps: float = 1e-3) -> Tuple[Tensor, Tensor]:
+    """fp64 {sum, sum of squares} [B,C,2] -> (mean, rstd) fp32 [B,C]."""
+    require_cuda(ws)
+    B, C, _ = ws.shape
+    mean = torch.empty((B, C), dtype=torch.float32, device=ws.device)
+    rstd = torch.empty_like(mean)
+    lib().call("omr_instnorm_finalize", ptr(ws), ptr(mean), ptr(rstd), B, HW, C, eps, cur_stream())
+    return mean, rstd
+
+
+def instnorm_bwd_apply(dxhat: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, ws: Tensor, relu_mask: bool, relu_scale: float = 1.0) -> Tensor:
+    """InstanceNorm backward apply step with the {sum g, sum g*xhat} sums already in ws (fp64 [B,C,2])."""
+    require_cuda(dxhat, x, ws)
+    B, H, W, C = x.shape
+    assert dxhat.shape == x.shape and dxhat.is_contiguous() and x.is_contiguous() and ws.dtype == torch.float64
+    dx = torch.empty_like(x)
+    lib().call("omr_instnorm_bwd_apply", dtype_code(x.dtype), ptr(dxhat), ptr(x), ptr(mean), ptr(rstd), ptr(dx), B, H * W, C, int(relu_mask),
+               float(relu_scale), ptr(ws), cur_stream())
+    return dx
+
+
 def instnorm_bwd(dxhat: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, relu_mask: bool, relu_scale: float = 1.0) -> Tensor:
     require_cuda(dxhat, x)
     B, H, W, C = x.shape
@@ -202,9 +223,12 @@ def conv_out_hw(H: int, W: int, stride: Tuple[int, int]) -> Tuple[int, int]:
 
 
 def conv3x3(x: Tensor, w_phys: Tensor, bias: Optional[Tensor], stride=(1, 1), relu: bool = False, in_stats=None, out_mask: Optional[Tensor] = None,
-            mask_scale: float = 1.0, dil=(1, 1), out_hw: Optional[Tuple[int, int]] = None) -> Tensor:
-    """x NHWC [B,H,W,CIN]; w_phys [COUT,3,3,CIN] contiguous; returns NHWC [B,Ho,Wo,COUT]."""
-    require_cuda(x, w_phys, bias, out_mask)
+            mask_scale: float = 1.0, dil=(1, 1), out_hw: Optional[Tuple[int, int]] = None, drop=None, stat_mode: int = 0,
+            stat_ws: Optional[Tensor] = None, stat_x: Optional[Tensor] = None, stat_stats=None) -> Tensor:
+    """x NHWC [B,H,W,CIN]; w_phys [COUT,3,3,CIN] contiguous; returns NHWC [B,Ho,Wo,COUT].
+    drop = (p, seed, channel_mode): fused dropout after the ReLU.  stat_mode 1/2: fused per-(image, channel) reductions of
+    the stored output into the fp64 buffer stat_ws [B,COUT,2] (see include/omr_hip.h)."""
+    require_cuda(x, w_phys, bias, out_mask, stat_ws, stat_x)
     B, H, W, CIN = x.shape
     COUT = w_phys.shape[0]
     assert x.is_contiguous() and w_phys.is_contiguous() and tuple(w_phys.shape) == (COUT, 3, 3, CIN) and w_phys.dtype == x.dtype
@@ -220,8 +244,16 @@ def conv3x3(x: Tensor, w_phys: Tensor, bias: Optional[Tensor], stride=(1, 1), re
         assert out_mask.shape == y.shape and out_mask.is_contiguous() and out_mask.dtype == x.dtype
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == COUT
+    p, seed, chan = drop if drop is not None else (0.0, 0, False)
+    smean = srstd = None
+    if stat_mode:
+        assert stat_ws is not None and stat_ws.dtype == torch.float64 and tuple(stat_ws.shape) == (B, COUT, 2) and stat_ws.is_contiguous()
+    if stat_mode == 2:
+        smean, srstd = stat_stats
+        assert stat_x is not None and stat_x.shape == y.shape and stat_x.is_contiguous() and tuple(smean.shape) == (B, COUT)
     lib().call("omr_conv3x3_fwd", dtype_code(x.dtype), ptr(x), ptr(w_phys), ptr(bias), ptr(y), ptr(mean), ptr(rstd), ptr(out_mask), float(mask_scale),
-               B, H, W, CIN, COUT, stride[0], stride[1], dil[0], dil[1], Ho, Wo, int(relu), cur_stream())
+               B, H, W, CIN, COUT, stride[0], stride[1], dil[0], dil[1], Ho, Wo, int(relu), float(p), int(seed) & (2**64 - 1), int(chan),
+               int(stat_mode), ptr(stat_ws), ptr(stat_x), ptr(smean), ptr(srstd), cur_stream())
     return y
 
 

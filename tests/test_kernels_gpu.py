@@ -397,3 +397,34 @@ def test_cross_entropy(dtype):
     torch.testing.assert_close(loss.cpu()[0], ref.detach(), rtol=1e-4 if dtype == torch.float32 else 1e-2, atol=1e-4)
     dl = K().ce_bwd(buf[:, :V], tgt.to(dev()), lse, acc2, V, 0)
     check(dl, logits.grad, dtype, scale=0.01, what="ce bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("channel_mode", [False, True])
+def test_conv3x3_fused_dropout_and_instnorm_reductions(dtype, channel_mode):
+    """The conv epilogue's fused MixDropout uses the same counter-based mask as omr_dropout, and its fused
+    per-(image, channel) reductions equal the stand-alone InstanceNorm statistics / backward kernels."""
+    B, C, H, W = 3, 32, 21, 45          # several tiles per image, ragged edges
+    k = K()
+    x = q(rnd((B, H, W, C), 90), dtype).to(dev(), dtype)
+    w = q(rnd((C, 3, 3, C), 91) / 12, dtype).to(dev(), dtype)
+    bias = rnd((C,), 92).to(dev())
+    y_plain = k.conv3x3(x, w, bias, relu=True)
+    ws = torch.zeros((B, C, 2), dtype=torch.float64, device=dev())
+    y = k.conv3x3(x, w, bias, relu=True, drop=(0.5, 77, channel_mode), stat_mode=1, stat_ws=ws)
+    ref = k.dropout(y_plain, 0.5, 77, channel_mode)
+    torch.testing.assert_close(y.float(), ref.float(), **tol(dtype))
+    mean, rstd = k.instnorm_finalize(ws, H * W)
+    mean_ref, rstd_ref = k.instnorm_stats(y)
+    torch.testing.assert_close(mean, mean_ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rstd, rstd_ref, rtol=1e-4, atol=1e-4)
+    # mode 2: backward sums fused into the data-gradient conv == stand-alone reduction + apply
+    g = q(rnd((B, H, W, C), 93), dtype).to(dev(), dtype)
+    wd = k.conv3x3_weight_flip(w)
+    dxh_ref = k.conv3x3(g, wd, None, out_hw=(H, W))
+    dx_ref = k.instnorm_bwd(dxh_ref, y, mean, rstd, relu_mask=True, relu_scale=2.0)
+    ws2 = torch.zeros((B, C, 2), dtype=torch.float64, device=dev())
+    dxh = k.conv3x3(g, wd, None, out_hw=(H, W), stat_mode=2, stat_ws=ws2, stat_x=y, stat_stats=(mean, rstd))
+    assert torch.equal(dxh, dxh_ref)
+    dx = k.instnorm_bwd_apply(dxh, y, mean, rstd, ws2, relu_mask=True, relu_scale=2.0)
+    torch.testing.assert_close(dx.float(), dx_ref.float(), **tol(dtype, 2))
