@@ -114,10 +114,16 @@ __device__ __forceinline__ bool attn_visible(const AttnArgs& a, int q, int key, 
     if (lq >= 0 && q >= lq && key >= lkv) return false;
     return true;
 }
-__device__ __forceinline__ float attn_keep(const AttnArgs& a, int b, int h, int q, int key) {
-    if (a.drop_thresh == 0) return 1.f;
-    const uint64_t idx = (((uint64_t)b * a.H + h) * a.T + q) * (uint64_t)a.S + key;
-    return drop_keep(a.seed, idx, a.drop_thresh) ? a.drop_scale : 0.f;
+// Attention-probability dropout mask (nn.MultiheadAttention dropout, decoder.py:91): keep(q, key) for head (b, h) is a
+// 5-op multiply-xorshift hash of the 32-bit index q*S + key keyed per (seed, b, h) -- forward and both backward kernels
+// regenerate exactly the same mask; nothing is stored.  `bh_key` is computed once per block with attn_bh_key().
+__device__ __forceinline__ uint32_t attn_bh_key(const AttnArgs& a, int b, int h) {
+    return hash32((uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)(b * a.H + h));
+}
+__device__ __forceinline__ float attn_keep(const AttnArgs& a, uint32_t bh_key, int q, int key) {
+    uint32_t x = ((uint32_t)q * (uint32_t)a.S + (uint32_t)key) ^ bh_key;
+    x *= 0x9E3779B1u; x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13;
+    return x >= a.drop_thresh ? a.drop_scale : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -148,6 +154,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         qf[ks] = q < a.T ? *reinterpret_cast<const F*>(Q + (long)q * a.ldq + ks * KS + hh * VEC) : frag_zero<T>();
     int lq = -1, lkv = 0;
     if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
+    const uint32_t bh_key = attn_bh_key(a, b, h);
 
     f32x16 acc_o[NDB];
 #pragma unroll
@@ -188,19 +195,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         const bool full = (kv0 + BKV <= a.S) && (qw0 + 32 <= a.T) && lq < 0 &&
                           (!a.causal || (kv0 + BKV - 1 <= qw0 && (!win_on || kv0 >= qw0 + 31 - a.window)));
         float mx = -INFINITY;
+        if (full) {          // wave-uniform: the unmasked tile never evaluates a visibility test
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bz = *reinterpret_cast<const f32x4*>(&bias_s[mb * 32 + 8 * g + 4 * hh]);
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bz = *reinterpret_cast<const f32x4*>(&bias_s[mb * 32 + 8 * g + 4 * hh]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float sv = fmaf(st[mb][4 * g + e], sc2, bz[e]);
-                    if (!full && !attn_visible(a, q, kv0 + mb * 32 + 8 * g + 4 * hh + e, lq, lkv)) sv = -INFINITY;
-                    st[mb][4 * g + e] = sv;
-                    mx = fmaxf(mx, sv);
+                    for (int e = 0; e < 4; ++e) {
+                        const float sv = fmaf(st[mb][4 * g + e], sc2, bz[e]);
+                        st[mb][4 * g + e] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
                 }
-            }
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bz = *reinterpret_cast<const f32x4*>(&bias_s[mb * 32 + 8 * g + 4 * hh]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float sv = fmaf(st[mb][4 * g + e], sc2, bz[e]);
+                        if (!attn_visible(a, q, kv0 + mb * 32 + 8 * g + 4 * hh + e, lq, lkv)) sv = -INFINITY;
+                        st[mb][4 * g + e] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
+                }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
@@ -218,14 +240,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[mb][r] *= attn_keep(a, b, h, q, kv0 + mb * 32 + acc_row(r, lane));
+                for (int r = 0; r < 16; ++r) st[mb][r] *= attn_keep(a, bh_key, q, kv0 + mb * 32 + acc_row(r, lane));
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (!__all(alpha == 1.f)) {      // the running max moved for some row of this wave: rescale the O accumulators
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
+            for (int d = 0; d < NDB; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+                for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+        }
         // O^T += V^T . P^T
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -304,6 +328,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     const int qw0 = q0 + wave * 32;
     int lq = -1, lkv = 0;
     if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
+    const uint32_t bh_key = attn_bh_key(a, b, h);
 
     f32x16 acc_q[NDB];
 #pragma unroll
@@ -337,19 +362,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 const F vf = *reinterpret_cast<const F*>(&Vs[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
                 mma32(dp, vf, dof[ks]);
             }
+            // P^T = exp2(score - lse) (0 where masked); wave-uniform branches keep the common tile free of mask / dropout tests
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 bz = *reinterpret_cast<const f32x4*>(&bias_s[mb * 32 + 8 * g + 4 * hh]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    float pv = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, bz[e]) - lse2);
-                    if (!full && !attn_visible(a, q, kv0 + mb * 32 + 8 * g + 4 * hh + e, lq, lkv)) pv = 0.f;
-                    float dpv = dp[r];
-                    if (drop) dpv *= attn_keep(a, b, h, q, kv0 + mb * 32 + 8 * g + 4 * hh + e);
-                    st[r] = pv * (dpv - dl);     // dS^T
-                }
+                for (int e = 0; e < 4; ++e) st[4 * g + e] = __builtin_amdgcn_exp2f(fmaf(st[4 * g + e], sc2, bz[e]) - lse2);
             }
+            if (!full) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (!attn_visible(a, q, kv0 + mb * 32 + acc_row(r, lane), lq, lkv)) st[r] = 0.f;
+            }
+            if (drop) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dp[r] *= attn_keep(a, bh_key, q, kv0 + mb * 32 + acc_row(r, lane));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = st[r] * (dp[r] - dl);     // dS^T
 #pragma unroll
             for (int s = 0; s < NFR; ++s) {
                 const F sf = acc_to_frag<T>(st, s);
@@ -409,6 +439,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int kw0 = k0 + wave * 32;
     int lq = -1, lkv = 0;
     if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
+    const uint32_t bh_key = attn_bh_key(a, b, h);
 
     f32x16 acc_k[NDB], acc_v[NDB];
 #pragma unroll
@@ -448,19 +479,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         f32x16 pd;  // dropped probabilities (for dV)
         const bool full = (kw0 + 32 <= a.S) && (q0 + BQ <= a.T) && lq < 0 &&
                           (!a.causal || (kw0 + 31 <= q0 && (!win_on || kw0 >= q0 + BQ - 1 - a.window)));
+        // one fused pass per element (few live registers); the wave-uniform `plain` branch carries no mask / dropout code
+        if (full && !drop) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lse_s[8 * g + 4 * hh]);   // already * log2 e
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(&del_s[8 * g + 4 * hh]);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lse_s[8 * g + 4 * hh]);   // already * log2 e
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(&del_s[8 * g + 4 * hh]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g + e, qq = q0 + 8 * g + 4 * hh + e;
-                float pv = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, kb2) - l4[e]);
-                if (!full && !attn_visible(a, qq, key, lq, lkv)) pv = 0.f;
-                float keep = 1.f;
-                if (drop) keep = attn_keep(a, b, h, qq, key);
-                pd[r] = pv * keep;
-                st[r] = pv * (dp[r] * keep - d4[e]);    // dS
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, kb2) - l4[e]);
+                    pd[r] = pv;
+                    st[r] = pv * (dp[r] - d4[e]);    // dS
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lse_s[8 * g + 4 * hh]);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(&del_s[8 * g + 4 * hh]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e, qq = q0 + 8 * g + 4 * hh + e;
+                    float pv = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, kb2) - l4[e]);
+                    if (!full && !attn_visible(a, qq, key, lq, lkv)) pv = 0.f;
+                    const float keep = drop ? attn_keep(a, bh_key, qq, key) : 1.f;
+                    pd[r] = pv * keep;
+                    st[r] = pv * (dp[r] * keep - d4[e]);    // dS = P o (M o dP - delta)
+                }
             }
         }
 #pragma unroll
