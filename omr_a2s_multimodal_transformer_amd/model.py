@@ -61,6 +61,16 @@ class PositionalEncoding2D(nn.Module):
         return y.permute(0, 3, 1, 2)
 
 
+def _h2d(t: torch.Tensor, device) -> torch.Tensor:
+    """Host -> device without blocking the host: a blocking copy would wait for the whole previous step (it drains the
+    stream) and stop the host from issuing the next step's launches while the GPU is still busy."""
+    if t.device == device:
+        return t
+    if not t.is_cuda and not t.is_pinned() and torch.cuda.is_available():
+        t = t.pin_memory()
+    return t.to(device, non_blocking=True)
+
+
 def _flatten_memory(x: torch.Tensor) -> torch.Tensor:
     """x.flatten(2).permute(0, 2, 1).contiguous() (model.py:147): free for channels_last-strided maps."""
     return x.flatten(2).permute(0, 2, 1).contiguous()
@@ -205,13 +215,13 @@ class Transformer(_Base):
     def encode(self, x: torch.Tensor) -> torch.Tensor:
         """encoder -> 2-D PE -> flatten -> [B, S, d] (model.py:143-147,176-180)."""
         flat = self.ensure_flat()
-        x = x.to(flat.device)
+        x = x.to(flat.device, non_blocking=True)
         f = self.encoder.forward_nhwc(x, flat.compute_dtype).permute(0, 3, 1, 2)
         return self._boundary(_flatten_memory(self.pos_2d(f)))
 
     def forward(self, x: torch.Tensor, xl: torch.Tensor, y_in: torch.Tensor) -> torch.Tensor:
         mem = self.encode(x)
-        return self.decoder(tgt=y_in.to(mem.device), memory=mem, memory_len=None if xl is None else xl.to(mem.device))
+        return self.decoder(tgt=_h2d(y_in, mem.device), memory=mem, memory_len=None if xl is None else _h2d(xl, mem.device))
 
     def apply_teacher_forcing(self, y: torch.Tensor) -> torch.Tensor:
         """model.py:152-160: each non-pad token is replaced w.p. teacher_forcing_prob by randint(0, V-1) drawn
@@ -224,13 +234,13 @@ class Transformer(_Base):
             for j, tok in enumerate(row):
                 if random.random() < self.teacher_forcing_prob and tok != self.padding_idx:
                     out[i, j] = random.randint(0, V - 1)
-        return out.to(y.device)
+        return out.pin_memory() if (not y.is_cuda and torch.cuda.is_available()) else out.to(y.device)
 
     def training_step(self, batch, batch_idx) -> torch.Tensor:
         x, xl, y_in, y_out = batch
         y_in = self.apply_teacher_forcing(y_in)
         yhat = self.forward(x=x, xl=xl, y_in=y_in)
-        loss = self.compute_loss(yhat, y_out.to(yhat.device))
+        loss = self.compute_loss(yhat, _h2d(y_out, yhat.device))
         self.log("train_loss", loss, prog_bar=True, logger=True, on_epoch=True)
         return loss
 
@@ -304,7 +314,7 @@ class MultimodalTransformer(_Base):
 
     def _encode(self, enc: Encoder, pos: PositionalEncoding2D, x: torch.Tensor) -> torch.Tensor:
         flat = self.ensure_flat()
-        f = enc.forward_nhwc(x.to(flat.device), flat.compute_dtype).permute(0, 3, 1, 2)
+        f = enc.forward_nhwc(_h2d(x, flat.device), flat.compute_dtype).permute(0, 3, 1, 2)
         return _flatten_memory(pos(f))
 
     def encoder_forward(self, xi, xa, xli=None, xla=None, apply_teacher_forcing_modality: bool = False):
@@ -327,7 +337,7 @@ class MultimodalTransformer(_Base):
 
     def forward(self, xi, xli, xa, xla, y_in, apply_teacher_forcing_modality: bool = False) -> torch.Tensor:
         x, xl = self.encoder_forward(xi=xi, xa=xa, xli=xli, xla=xla, apply_teacher_forcing_modality=apply_teacher_forcing_modality)
-        return self.decoder(tgt=y_in.to(x.device), memory=x, memory_len=None if xl is None else xl.to(x.device))
+        return self.decoder(tgt=_h2d(y_in, x.device), memory=x, memory_len=None if xl is None else _h2d(xl, x.device))
 
     def apply_teacher_forcing(self, y: torch.Tensor) -> torch.Tensor:
         """model.py:545-559 (vectorised, torch RNG)."""
@@ -346,7 +356,7 @@ class MultimodalTransformer(_Base):
         xi, xli, xa, xla, y_in, y_out = batch
         y_in = self.apply_teacher_forcing(y_in)
         yhat = self.forward(xi=xi, xli=xli, xa=xa, xla=xla, y_in=y_in, apply_teacher_forcing_modality=True)
-        loss = self.compute_loss(yhat, y_out.to(yhat.device))
+        loss = self.compute_loss(yhat, _h2d(y_out, yhat.device))
         self.log("train_loss", loss, prog_bar=True, logger=True, on_epoch=True)
         return loss
 
