@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     constexpr bool TR = std::is_same<T, bf16>::value;       // bf16: transposing LDS reads; fp32: element gathers
     // LDS pitches (elements).  tr path: 4 consecutive pixel rows x 16 dwords must tile the 64 banks -> 64 B rows for 32
     // channels, 192 B rows for 64 channels (conflict-free for unit pixel stride); scalar path: odd dword pitch.
-    constexpr int NP = TR ? (CBN == 32 ? 32 : 96) : CBN + 4, CP = TR ? (CBC == 32 ? 32 : 96) : CBC + 4;
+    constexpr int NP = TR ? CBN + 8 : CBN + 4, CP = TR ? CBC + 8 : CBC + 4;   // +16 B: conflict-free 16-byte staging stores, 2-way at worst on the tr reads
     typedef __attribute__((address_space(3))) bf16x4 LdsV4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3, NPIX = IH * IW;   // compile-time tile geometry
@@ -208,7 +208,7 @@ template <typename T, int TH, int CBN, int CBC, int SH, int SW> int launch_wgrad
     a.tiles_h = cdiv(a.Ho, TH);
     constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3;
     constexpr bool TR = std::is_same<T, bf16>::value;
-    constexpr int NP = TR ? (CBN == 32 ? 32 : 96) : CBN + 4, CP = TR ? (CBC == 32 ? 32 : 96) : CBC + 4;
+    constexpr int NP = TR ? CBN + 8 : CBN + 4, CP = TR ? CBC + 8 : CBC + 4;   // +16 B: conflict-free 16-byte staging stores, 2-way at worst on the tr reads
     size_t shm = ((size_t)TH * TW * NP + (size_t)IH * IW * CP) * sizeof(T);
     if (shm > 160 * 1024) return OMR_ERR_UNSUPPORTED;
     auto kern = conv3x3_wgrad_kernel<T, TH, CBN, CBC, SH, SW>;
@@ -217,7 +217,13 @@ template <typename T, int TH, int CBN, int CBC, int SH, int SW> int launch_wgrad
     }
     const int gy = cdiv(a.COUT, CBN) * cdiv(a.CIN, CBC);
     const int ntiles = a.B * a.tiles_h * a.tiles_w;
-    int gx = 1024 / gy; if (gx < 1) gx = 1; if (gx > ntiles) gx = ntiles;
+    static int occ_cache = 0;            // resident blocks per CU of this instantiation: the persistent grid fills the chip once
+    if (occ_cache == 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, shm) != hipSuccess || occ < 1) occ = 2;
+        occ_cache = occ;
+    }
+    int gx = (256 * occ_cache + gy - 1) / gy; if (gx < 1) gx = 1; if (gx > ntiles) gx = ntiles;
     hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), shm, s, a);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
