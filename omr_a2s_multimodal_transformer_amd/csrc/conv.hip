@@ -16,6 +16,7 @@
 #include "omr_hip.h"
 
 #include "conv3x3_mfma.h"
+#include "conv_wgrad.h"
 
 using omr_conv::ConvArgs;
 using omr_conv::TW;
@@ -41,12 +42,6 @@ __global__ void weight_flip_kernel(const T* __restrict__ w, T* __restrict__ wd, 
 // block (n0 + 32 wn, c0 + 32 wc) for all nine taps (9 x 16 accumulator registers).  K = output pixels:
 // the block walks pixel tiles (grid-stride), stages dY[pix][64 n] and the X halo [pix][64 c] in LDS
 // and reads k-strided operand fragments element-wise (dtype generic; bf16 tr-reads are a later step).
-struct WgradArgs {
-    const void* x; const void* dy; float* dw; float* db;
-    const float* mean; const float* rstd;
-    int B, Hr, Wr, CIN, Ho, Wo, COUT, sh, sw, tiles_w, tiles_h;
-};
-
 template <typename T, int TH, int CBN, int CBC, int SH, int SW>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
     typedef typename Frag<T>::type F;
@@ -550,7 +545,11 @@ extern "C" int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float
     WgradArgs a;
     a.x = x; a.dy = dy; a.dw = dw; a.db = db; a.mean = in_mean; a.rstd = in_rstd; a.B = B; a.Hr = H; a.Wr = W; a.CIN = CIN; a.Ho = Ho; a.Wo = Wo;
     a.COUT = COUT; a.sh = stride_h; a.sw = stride_w; a.tiles_w = a.tiles_h = 0;
-    if (dtype == OMR_BF16) return launch_wgrad<bf16, 8, 4>(a, s);
+    if (dtype == OMR_BF16) {
+        const int rc = omr_wgrad_dma_bf16(a, s);            // asynchronous-staging kernel (conv_wgrad_dma.hip) where it covers the shape
+        if (rc != OMR_ERR_UNSUPPORTED) return rc;
+        return launch_wgrad<bf16, 8, 4>(a, s);
+    }
     if (dtype == OMR_F32) return launch_wgrad<float, 4, 2>(a, s);
     return OMR_ERR_UNSUPPORTED;
 }

@@ -33,8 +33,14 @@ def wt(p: Tensor, dtype: torch.dtype) -> Tensor:
     return lp
 
 
-def split_k_for(m_red: int) -> int:
-    return max(1, min(128, (m_red + 255) // 256))
+def split_k_for(m_red: int, out_rows: int = 128, out_cols: int = 128) -> int:
+    """Split-K factor of a weight-gradient GEMM reducing over m_red rows into an [out_rows, out_cols] matrix: about
+    384 blocks in flight (128x128 tiles x splits), at least 256 reduction rows per split, power of two.  Fewer splits
+    starve the CUs (the main loop is latency-bound), more splits drown in fp32 atomics (measured: tools/gemm_splitk_sweep.py)."""
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+    want = max(8, 384 // tiles)
+    sk = 1 << (want.bit_length() - 1)
+    return max(1, min(sk, (m_red + 255) // 256))
 
 
 # ------------------------------------------------------------------------------------------------ encoder
@@ -163,7 +169,7 @@ class LinearFn(Function):
         if relu and mask_own:
             g2 = K.relu_bwd(g2.contiguous(), y2)
         M = g2.shape[0]
-        K.gemm(g2, x2, trans_a=True, trans_b=True, out=gw, accumulate=True, split_k=split_k_for(M), colsum_a=gb)   # dW and db in one pass
+        K.gemm(g2, x2, trans_a=True, trans_b=True, out=gw, accumulate=True, split_k=split_k_for(M, N, Kd), colsum_a=gb)   # dW and db in one pass
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.gemm(g2, w, trans_b=True).view(xshape)

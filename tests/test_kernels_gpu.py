@@ -201,6 +201,7 @@ def nhwc(t):
 CONV_CASES = [  # CIN, COUT, stride, H, W
     (1, 16, (1, 1), 13, 45), (16, 16, (1, 1), 11, 37), (16, 32, (1, 1), 9, 33), (32, 32, (2, 2), 13, 41), (64, 64, (2, 2), 12, 70),
     (64, 128, (1, 1), 7, 35), (128, 128, (2, 1), 9, 34), (128, 128, (2, 2), 8, 36),
+    (32, 32, (1, 1), 17, 70), (32, 64, (1, 1), 9, 40), (64, 32, (1, 1), 10, 33), (128, 128, (1, 1), 19, 65),
 ]
 
 
