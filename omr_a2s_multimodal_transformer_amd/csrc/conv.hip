@@ -181,9 +181,17 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs a) {
             }
         }
     }
-    if (do_bias) {
-        const int n = n0 + tid % CBN;
-        if (n < a.COUT) atomicAdd(&a.db[n], bsum);
+    if (do_bias) {   // combine the per-thread partial sums in LDS first: lanes of one wave hitting the same address serialise badly
+        float* red = reinterpret_cast<float*>(smem_raw);
+        __syncthreads();
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < CBN) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 256 / CBN; ++k) v += red[k * CBN + tid];
+            if (n0 + tid < a.COUT) atomicAdd(&a.db[n0 + tid], v);
+        }
     }
     // accumulate: dw[n][tap][c] (fp32 atomics; the grad buffer is zeroed once per step)
     const int c = c0 + wc * 32 + (lane & 31);
@@ -530,7 +538,7 @@ extern "C" int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float
     hipStream_t s = (hipStream_t)stream;
     if (CIN == 1) {
         if (stride_h != 1 || stride_w != 1 || in_mean) return OMR_ERR_UNSUPPORTED;
-        int gy = B * H; if (gy > 128) gy = 128;
+        int gy = B * H; if (gy > 32) gy = 32;      // few, long-lived blocks: each ends with 10 COUT atomics onto the same five cache lines
         dim3 grid(cdiv(W, 85), gy);
         DISPATCH_T(dtype, {
             if (COUT == 16) hipLaunchKernelGGL((conv1_wgrad_kernel<T, 16>), grid, 256, 0, s, (const T*)x, (const T*)dy, dw, db, B, H, W);

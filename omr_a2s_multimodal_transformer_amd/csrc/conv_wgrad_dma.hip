@@ -54,13 +54,31 @@ template <int PENDING> __device__ __forceinline__ void dma_wait_barrier() {
 }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// XOR swizzle of the 16-byte chunk index inside a 128-byte row: the 4 consecutive pixel rows of one transposing read
-// then cover all 64 banks.  Narrower rows are conflict-free as they lie.
-template <int CB> __device__ __forceinline__ int swz(int pix) { return CB == 64 ? ((pix >> 1) & 1) << 2 : 0; }
-template <int CB> __device__ __forceinline__ int lds_off(int pix, int ch) { return pix * CB + ((((ch >> 3) ^ swz<CB>(pix)) << 3) | (ch & 7)); }
+// Placement of 16-byte chunk c of tile pixel `pix` inside a dense [pixel][CB] LDS tile.  Each lane of the DMA chooses its
+// own global source, so bank conflicts are removed by permuting where a chunk lands instead of padding rows:
+//   * the 4 pixel rows x 64 bytes that half a wave touches in one transposing read must cover all 64 banks (256 B);
+//   * unit pixel step (dY tiles, X tiles of stride-1 convs): rows narrower than 128 B are conflict-free as they lie;
+//     128-byte rows swap their 64-byte halves on every other pixel pair;
+//   * pixel step 2 (X tiles of the strided convs): the four rows share their parity, so additionally neighbouring pixels
+//     swap places on every other group of four.
+// PS = pixel step of the reads (1 or 2).  Both maps are involutions on (pix, c), so the DMA uses the same function to
+// find the source of an LDS slot.
+template <int CB, int PS> struct Place {
+    static constexpr int CPP = CB / 8;
+    __device__ static __forceinline__ int pixel(int pix) { return (PS == 2 && CB >= 32) ? pix ^ ((pix >> 2) & 1) : pix; }
+    __device__ static __forceinline__ int chunk(int pix, int c) { return CB == 64 ? c ^ (((pix >> 1) & 1) << 2) : c; }
+    // element offset of channel ch of pixel pix
+    __device__ static __forceinline__ int off(int pix, int ch) { return pixel(pix) * CB + ((chunk(pix, ch >> 3) << 3) | (ch & 7)); }
+    // LDS chunk slot L -> (pix, c) stored there
+    __device__ static __forceinline__ void source(int L, int& pix, int& c) {
+        pix = pixel(L / CPP);
+        c = chunk(pix, L % CPP);
+    }
+};
 
 template <int CB, int NPIXT, int NTHR> struct TileDma {
-    static constexpr int CPP = CB / 8, NCH = NPIXT * CPP, ROUNDS = (NCH + NTHR - 1) / NTHR;
+    // the placement may swap a pixel with its pair neighbour, so slots exist for an even number of pixels
+    static constexpr int CPP = CB / 8, NCH = (NPIXT + 1) / 2 * 2 * CPP, ROUNDS = (NCH + NTHR - 1) / NTHR;
     static constexpr int ELEMS = (NCH + 63) / 64 * 64 * 8;   // LDS footprint: whole wave instructions (tail lanes fetch zeros)
 };
 
@@ -71,7 +89,7 @@ template <int CB, int NPIXT, int NTHR> struct TileDma {
 // Every wave issues exactly ROUNDS instructions with all lanes active (lanes without a source read g_zero16, waves whose
 // 64 chunks lie wholly past the tile write a shared 1 KB scratch), so the number of DMA instructions in flight is a
 // compile-time quantity the waits can count on.
-template <int CB, int IWT, int NPIXT, int NTHR> struct TileIssuer {
+template <int CB, int PS, int IWT, int NPIXT, int NTHR> struct TileIssuer {
     typedef TileDma<CB, NPIXT, NTHR> D;
     int rel[D::ROUNDS];     // element offset of the source chunk from the tile origin; -1: none (pad lane / channel tail)
     int ij[D::ROUNDS];      // tile row | tile column << 16
@@ -79,10 +97,11 @@ template <int CB, int IWT, int NPIXT, int NTHR> struct TileIssuer {
 #pragma unroll
         for (int r = 0; r < D::ROUNDS; ++r) {
             const int L = r * NTHR + tid;                   // LDS chunk this lane fills
-            const int pix = L / D::CPP, c = (L % D::CPP) ^ swz<CB>(pix);
+            int pix, c;
+            Place<CB, PS>::source(L, pix, c);
             const int il = pix / IWT, jl = pix - il * IWT;
             ij[r] = il | (jl << 16);
-            rel[r] = (L < D::NCH && c * 8 < cvalid) ? (il * Wimg + jl) * C + c * 8 : -1;
+            rel[r] = (L < D::NCH && pix < NPIXT && c * 8 < cvalid) ? (il * Wimg + jl) * C + c * 8 : -1;
         }
     }
     // origin = address of image pixel (y0, x0) (may lie outside the image: only in-bounds lanes dereference their offset)
@@ -134,8 +153,10 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
     const bf16* X = (const bf16*)a.x;
     const bf16* DY = (const bf16*)a.dy;
 
-    TileIssuer<CBN, TW, NPY, NTHR> iy;
-    TileIssuer<CBC, IW, NPX, NTHR> ix;
+    TileIssuer<CBN, 1, TW, NPY, NTHR> iy;
+    TileIssuer<CBC, SW, IW, NPX, NTHR> ix;
+    typedef Place<CBN, 1> PY;
+    typedef Place<CBC, SW> PX;
     iy.init(a.Wo, a.COUT, a.COUT - n0, tid);
     ix.init(a.Wr, a.CIN, a.CIN - c0, tid);
     const float inv_tpi = 1.0f / (float)tiles_per_img, inv_tw = 1.0f / (float)a.tiles_w;
@@ -195,9 +216,10 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
             issue(tile + (NSTAGE - 1) * (int)gridDim.x, nslot);
             const int th = fdiv(rem, a.tiles_w, inv_tw);
             const int ih0 = th * TH * SH - 1, iw0 = (rem - th * a.tiles_w) * TW * SW - 1;
-            constexpr int CPP = CBC / 8, NCH = NPX * CPP;
-            for (int L = tid; L < NCH; L += NTHR) {
-                const int pix = L / CPP, c = (L % CPP) ^ swz<CBC>(pix);
+            for (int L = tid; L < DX_::NCH; L += NTHR) {
+                int pix, c;
+                PX::source(L, pix, c);
+                if (pix >= NPX) continue;
                 const int il = pix / IW, jl = pix - il * IW;
                 const int ih = ih0 + il, iw = iw0 + jl;
                 if (ih < 0 || ih >= a.Hr || iw < 0 || iw >= a.Wr || c0 + c * 8 >= a.CIN) continue;
@@ -213,20 +235,20 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
         if (do_bias && !DBG(4)) {   // bias gradient: column sums of the staged dY tile (thread = channel x pixel phase)
             constexpr int NPH = NTHR / CBN;
             const int ch = tid % CBN;
-            for (int pix = tid / CBN; pix < NPY; pix += NPH) bsum += (float)Ys[lds_off<CBN>(pix, ch)];
+            for (int pix = tid / CBN; pix < NPY; pix += NPH) bsum += (float)Ys[PY::off(pix, ch)];
         }
 #pragma unroll(NPY / 16 / WK <= 2 ? 2 : 1)
         for (int k0 = wk * 16; k0 < (DBG(2) ? 0 : NPY); k0 += WK * 16) {
             const int pk = k0 + 8 * hh + q;                  // pixels pk..pk+3 (u = 0) and pk+4..pk+7 (u = 1), same tile row
-            const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(Ys + lds_off<CBN>(pk, cha)));
-            const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(Ys + lds_off<CBN>(pk + 4, cha)));
+            const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(Ys + PY::off(pk, cha)));
+            const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(Ys + PY::off(pk + 4, cha)));
             const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
             const int xp = ((pk >> 5) * SH) * IW + (pk & 31) * SW;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int px = xp + (tap / 3) * IW + (tap % 3);
-                const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(Xs + lds_off<CBC>(px, chb)));
-                const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(Xs + lds_off<CBC>(px + 4 * SW, chb)));
+                const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(Xs + PX::off(px, chb)));
+                const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(Xs + PX::off(px + 4 * SW, chb)));
                 const bf16x8 bf = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
                 mma32(acc[tap], af, bf);
             }
@@ -313,6 +335,15 @@ template <int SH, int SW, bool NORM> int pick(const WgradArgs& a, hipStream_t s)
         if (cn == 32 && cc == 16) return launch<32, 16, 8, 1, 1, 8, 5, NORM>(a, s);
         if (cn == 16 && cc == 16) return launch<16, 16, 8, 1, 1, 8, 6, NORM>(a, s);
     }
+    if constexpr (SH == 2 && SW == 2) {   // input tile is 4x the output tile: fewer rows per tile
+        if (cn == 64 && cc == 64) return launch<64, 64, 2, 2, 2, 8, 3, NORM>(a, s);
+        if (cn == 32 && cc == 32) return launch<32, 32, 4, 2, 2, 8, 3, NORM>(a, s);
+        if (cn == 16 && cc == 16) return launch<16, 16, 8, 2, 2, 8, 3, NORM>(a, s);
+    }
+    if constexpr (SH == 2 && SW == 1) {
+        if (cn == 64 && cc == 64) return launch<64, 64, 4, 2, 1, 8, 2, NORM>(a, s);
+        if (cn == 32 && cc == 32) return launch<32, 32, 8, 2, 1, 8, 2, NORM>(a, s);
+    }
     return OMR_ERR_UNSUPPORTED;
 }
 
@@ -322,5 +353,7 @@ int omr_wgrad_dma_bf16(const WgradArgs& a, hipStream_t s) {
     if (a.CIN % 8 || a.COUT % 8) return OMR_ERR_UNSUPPORTED;
     const bool norm = a.mean != nullptr;
     if (a.sh == 1 && a.sw == 1) return norm ? pick<1, 1, true>(a, s) : pick<1, 1, false>(a, s);
+    if (a.sh == 2 && a.sw == 2) return norm ? pick<2, 2, true>(a, s) : pick<2, 2, false>(a, s);
+    if (a.sh == 2 && a.sw == 1) return norm ? pick<2, 1, true>(a, s) : pick<2, 1, false>(a, s);
     return OMR_ERR_UNSUPPORTED;
 }

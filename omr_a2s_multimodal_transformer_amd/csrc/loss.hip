@@ -7,37 +7,73 @@
 
 namespace {
 
+// One workgroup per row: a single vectorised pass keeps a running (max, sum of exp) per thread (online softmax), then
+// combines across the workgroup.  Only lse[row] is written: the loss itself is reduced by ce_finalize_kernel in a fixed
+// order (no atomics: device-scope atomics on one address serialise at the memory side, and the sum stays deterministic).
 template <typename T>
-__global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logits, const long* __restrict__ target, float* __restrict__ lse,
-                                                     double* __restrict__ acc /* [0]=sum loss, [1]=count */, int V, long ldv, int pad_idx) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logits, float* __restrict__ lse, int V, long ldv) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N;
+    __shared__ float red_m[4], red_s[4];
     const long row = blockIdx.x;
     const T* lr = logits + row * ldv;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float mx = -INFINITY;
-    for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, to_f32(lr[v]));
-    mx = wave_max(mx);
-    if (lane == 0) red[wv] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float s = 0.f;
-    for (int v = threadIdx.x; v < V; v += 256) s += __expf(to_f32(lr[v]) - mx);
-    s = wave_sum(s);
-    if (lane == 0) red[wv] = s;
+    float mx = -INFINITY, s = 0.f;
+    const bool vec_ok = (ldv % VEC) == 0 && (((uintptr_t)logits) & 15) == 0;
+    if (vec_ok) {
+        for (int v0 = threadIdx.x * VEC; v0 < V; v0 += 256 * VEC) {
+            const F f = *reinterpret_cast<const F*>(lr + v0);      // v0 + VEC <= ldv: the padding columns are readable
+            float x[VEC], cm = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { x[e] = (v0 + e < V) ? to_f32(f[e]) : -INFINITY; cm = fmaxf(cm, x[e]); }
+            const float nm = fmaxf(mx, cm);
+            float add = 0.f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) add += __expf(x[e] - nm);
+            s = s * __expf(mx - nm) + add;
+            mx = nm;
+        }
+    } else {
+        for (int v = threadIdx.x; v < V; v += 256) {
+            const float x = to_f32(lr[v]), nm = fmaxf(mx, x);
+            s = s * __expf(mx - nm) + __expf(x - nm);
+            mx = nm;
+        }
+    }
+    const float wm = wave_max(mx);
+    s = wave_sum(mx == -INFINITY ? 0.f : s * __expf(mx - wm));
+    if (lane == 0) { red_m[wv] = wm; red_s[wv] = s; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float l = mx + logf(red[0] + red[1] + red[2] + red[3]);
-        lse[row] = l;
-        long t = target[row];
-        if (t != pad_idx && t >= 0 && t < V) {
-            atomicAdd(&acc[0], (double)(l - to_f32(lr[t])));
-            atomicAdd(&acc[1], 1.0);
-        }
+        const float m = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t += red_m[i] == -INFINITY ? 0.f : red_s[i] * __expf(red_m[i] - m);
+        lse[row] = m + logf(t);
     }
 }
 
-__global__ void ce_finalize_kernel(const double* __restrict__ acc, float* __restrict__ loss) { loss[0] = (float)(acc[0] / acc[1]); }
+// acc[0] = sum over live rows of lse - logit[target], acc[1] = number of live rows, loss = mean.  One workgroup, fixed order.
+template <typename T>
+__global__ __launch_bounds__(1024) void ce_finalize_kernel(const T* __restrict__ logits, const long* __restrict__ target, const float* __restrict__ lse,
+                                                           double* __restrict__ acc, float* __restrict__ loss, long M, int V, long ldv, int pad_idx) {
+    __shared__ double rs[16], rc[16];
+    double s = 0.0, c = 0.0;
+    for (long row = threadIdx.x; row < M; row += 1024) {
+        const long t = target[row];
+        if (t != pad_idx && t >= 0 && t < V) { s += (double)(lse[row] - to_f32(logits[row * ldv + t])); c += 1.0; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0.0, tc = 0.0;
+        for (int i = 0; i < 16; ++i) { ts += rs[i]; tc += rc[i]; }
+        acc[0] = ts; acc[1] = tc;
+        loss[0] = (float)(ts / tc);
+    }
+}
 
 // dlogits = (softmax - onehot) * gscale / count on rows whose target != PAD, else 0.
 template <typename T>
@@ -64,11 +100,13 @@ extern "C" int omr_ce_fwd(int dtype, const void* logits, const long* target, flo
                           int pad_idx, void* stream) {
     if (M <= 0 || V <= 0 || ldv < V) return OMR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(acc2, 0, 2 * sizeof(double), s) != hipSuccess) return OMR_ERR_LAUNCH;
-    if (dtype == OMR_F32) hipLaunchKernelGGL((ce_fwd_kernel<float>), (int)M, 256, 0, s, (const float*)logits, target, lse, acc2, V, ldv, pad_idx);
-    else if (dtype == OMR_BF16) hipLaunchKernelGGL((ce_fwd_kernel<bf16>), (int)M, 256, 0, s, (const bf16*)logits, target, lse, acc2, V, ldv, pad_idx);
-    else return OMR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(ce_finalize_kernel, 1, 1, 0, s, (const double*)acc2, loss_out);
+    if (dtype == OMR_F32) {
+        hipLaunchKernelGGL((ce_fwd_kernel<float>), (int)M, 256, 0, s, (const float*)logits, lse, V, ldv);
+        hipLaunchKernelGGL((ce_finalize_kernel<float>), 1, 1024, 0, s, (const float*)logits, target, (const float*)lse, acc2, loss_out, M, V, ldv, pad_idx);
+    } else if (dtype == OMR_BF16) {
+        hipLaunchKernelGGL((ce_fwd_kernel<bf16>), (int)M, 256, 0, s, (const bf16*)logits, lse, V, ldv);
+        hipLaunchKernelGGL((ce_finalize_kernel<bf16>), 1, 1024, 0, s, (const bf16*)logits, target, (const float*)lse, acc2, loss_out, M, V, ldv, pad_idx);
+    } else return OMR_ERR_UNSUPPORTED;
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }

@@ -236,25 +236,26 @@ def test_conv3x3_fwd_bwd(dtype, cin, cout, stride, H, W):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_conv3x3_fused_instnorm(dtype):
-    B, C, H, W = 2, 32, 10, 40
+@pytest.mark.parametrize("C,stride,H,W", [(32, (2, 2), 10, 40), (64, (2, 2), 12, 70), (128, (2, 1), 9, 34), (16, (1, 1), 19, 45), (128, (2, 2), 7, 33)])
+def test_conv3x3_fused_instnorm(dtype, C, stride, H, W):
+    B = 2
     x = q(F.relu(rnd((B, C, H, W), 34)), dtype).requires_grad_(True)
     w = q(rnd((C, C, 3, 3), 35) / 12, dtype).requires_grad_(True)
     xh = R.instance_norm(x)
     xh.retain_grad()
-    pre = F.conv2d(xh, w, None, stride=(2, 2), padding=1)
+    pre = F.conv2d(xh, w, None, stride=stride, padding=1)
     k = K()
     xg = nhwc(x.detach()).to(dev(), dtype)
     wg = w.detach().permute(0, 2, 3, 1).contiguous().to(dev(), dtype)
     stats = k.instnorm_stats(xg)
-    yg = k.conv3x3(xg, wg, None, stride=(2, 2), in_stats=stats)
+    yg = k.conv3x3(xg, wg, None, stride=stride, in_stats=stats)
     check(yg, nhwc(pre), dtype, scale=2, what="norm+conv fwd")
     g = q(rnd(tuple(pre.shape), 36), dtype)
     pre.backward(g)
     dw = torch.zeros((C, 3, 3, C), device=dev())
-    k.conv3x3_wgrad(xg, nhwc(g).to(dev(), dtype), dw, stride=(2, 2), in_stats=stats)
+    k.conv3x3_wgrad(xg, nhwc(g).to(dev(), dtype), dw, stride=stride, in_stats=stats)
     check(dw, w.grad.permute(0, 2, 3, 1), dtype, scale=8, what="norm+conv wgrad")
-    dxh = k.conv3x3(nhwc(g).to(dev(), dtype), k.conv3x3_weight_flip(wg), None, dil=(2, 2), out_hw=(H, W))
+    dxh = k.conv3x3(nhwc(g).to(dev(), dtype), k.conv3x3_weight_flip(wg), None, dil=stride, out_hw=(H, W))
     check(dxh, nhwc(xh.grad), dtype, scale=2, what="norm+conv dgrad")
     dx = k.instnorm_bwd(dxh, xg, stats[0], stats[1], relu_mask=False)
     check(dx, nhwc(x.grad), dtype, scale=8, what="norm bwd chain")
