@@ -79,31 +79,39 @@ template <typename T> __device__ __forceinline__ typename Frag<T>::type acc_to_f
     return f;
 }
 
-// Stage rows [r0, r0+NR) x HD of a [rows][ld] matrix into LDS row-major (pitch P), zero beyond nrows.
-template <typename T, int HD, int NR, int P>
-__device__ __forceinline__ void stage_rows(T* lds, const T* src, long ld, int r0, int nrows, int tid) {
+// Register-staged tile of NR rows x HD: load() issues the global reads (rows beyond nrows read as zero), store() /
+// store_t() commit them to LDS row-major / transposed.  The kernels load tile t+1 right after the barrier that publishes
+// tile t, so the HBM latency of the next tile is hidden behind the MFMA / softmax work on the current one.
+template <typename T, int HD, int NR> struct RowTile {
     typedef typename Frag<T>::type F;
-    constexpr int VEC = Frag<T>::N, CPR = HD / VEC;
-    for (int c = tid; c < NR * CPR; c += 256) {
-        const int r = c / CPR, kc = (c % CPR) * VEC;
-        F v = frag_zero<T>();
-        if (r0 + r < nrows) v = *reinterpret_cast<const F*>(src + (long)(r0 + r) * ld + kc);
-        *reinterpret_cast<F*>(lds + r * P + kc) = v;
-    }
-}
-// Same tile transposed: lds[d][r] (pitch P over r).
-template <typename T, int HD, int NR, int P>
-__device__ __forceinline__ void stage_rows_t(T* lds, const T* src, long ld, int r0, int nrows, int tid) {
-    typedef typename Frag<T>::type F;
-    constexpr int VEC = Frag<T>::N, CPR = HD / VEC;
-    for (int c = tid; c < NR * CPR; c += 256) {
-        const int r = c / CPR, kc = (c % CPR) * VEC;
-        F v = frag_zero<T>();
-        if (r0 + r < nrows) v = *reinterpret_cast<const F*>(src + (long)(r0 + r) * ld + kc);
+    static constexpr int VEC = Frag<T>::N, CPR = HD / VEC, NCH = (NR * CPR + 255) / 256;
+    F r[NCH];
+    __device__ __forceinline__ void load(const T* src, long ld, int r0, int nrows, int tid) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) lds[(kc + e) * P + r] = v[e];
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * 256, row = c / CPR, kc = (c % CPR) * VEC;
+            r[i] = frag_zero<T>();
+            if (c < NR * CPR && r0 + row < nrows) r[i] = *reinterpret_cast<const F*>(src + (long)(r0 + row) * ld + kc);
+        }
     }
-}
+    template <int P> __device__ __forceinline__ void store(T* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * 256, row = c / CPR, kc = (c % CPR) * VEC;
+            if (c < NR * CPR) *reinterpret_cast<F*>(lds + row * P + kc) = r[i];
+        }
+    }
+    template <int P> __device__ __forceinline__ void store_t(T* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + i * 256, row = c / CPR, kc = (c % CPR) * VEC;
+            if (c < NR * CPR) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) lds[(kc + e) * P + row] = r[i][e];
+            }
+        }
+    }
+};
 
 __device__ __forceinline__ bool attn_visible(const AttnArgs& a, int q, int key, int lq, int lkv) {
     if (key >= a.S || q >= a.T) return false;
@@ -114,17 +122,22 @@ __device__ __forceinline__ bool attn_visible(const AttnArgs& a, int q, int key, 
     if (lq >= 0 && q >= lq && key >= lkv) return false;
     return true;
 }
-// Attention-probability dropout mask (nn.MultiheadAttention dropout, decoder.py:91): keep(q, key) for head (b, h) is a
-// 5-op multiply-xorshift hash of the 32-bit index q*S + key keyed per (seed, b, h) -- forward and both backward kernels
-// regenerate exactly the same mask; nothing is stored.  `bh_key` is computed once per block with attn_bh_key().
+// Attention-probability dropout mask (nn.MultiheadAttention dropout, decoder.py:91).  The softmax kernels are VALU-bound
+// (hd = 64: ~20 vector ops per score against 2 MFMA issue slots), so the mask is as cheap as it gets: ONE 7-op
+// multiply-xorshift hash of the pair index (q, key >> 1), keyed per (seed, b, h), decides two adjacent keys with 16 bits
+// each (keep iff bits >= p * 2^16).  Forward and both backward kernels regenerate exactly the same mask; nothing is
+// stored.  The 1/(1-p) rescale is folded out of the per-score code (applied to O / dV / inside an fma).
 __device__ __forceinline__ uint32_t attn_bh_key(const AttnArgs& a, int b, int h) {
     return hash32((uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)(b * a.H + h));
 }
-__device__ __forceinline__ float attn_keep(const AttnArgs& a, uint32_t bh_key, int q, int key) {
-    uint32_t x = ((uint32_t)q * (uint32_t)a.S + (uint32_t)key) ^ bh_key;
-    x *= 0x9E3779B1u; x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13;
-    return x >= a.drop_thresh ? a.drop_scale : 0.f;
+// 32 random bits for the key pair (key & ~1, key | 1) of query q: low half = even key, high half = odd key
+__device__ __forceinline__ uint32_t attn_rand2(uint32_t bh_key, uint32_t pair_idx) {
+    uint32_t x = pair_idx ^ bh_key;
+    x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 16;
+    return x;
 }
+__device__ __forceinline__ bool attn_keep_lo(uint32_t x, uint32_t thr16) { return (x & 0xffffu) >= thr16; }
+__device__ __forceinline__ bool attn_keep_hi(uint32_t x, uint32_t thr16) { return (x >> 16) >= thr16; }
 
 // ------------------------------------------------------------------------------------------------
 // Forward.  grid = (ceil(T/128), H, B); wave w owns query rows q0 + 32w .. +31; KV tiles of 64 keys.
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         qf[ks] = q < a.T ? *reinterpret_cast<const F*>(Q + (long)q * a.ldq + ks * KS + hh * VEC) : frag_zero<T>();
     int lq = -1, lkv = 0;
     if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
-    const uint32_t bh_key = attn_bh_key(a, b, h);
+    const uint32_t bh_key = attn_bh_key(a, b, h), s2 = (uint32_t)(a.S + 1) >> 1;
 
     f32x16 acc_o[NDB];
 #pragma unroll
@@ -170,13 +183,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         kv_end = min(a.S, q0 + 128);
         if (a.window > 0 && a.window < a.T) kv_beg = max(0, q0 - a.window) / BKV * BKV;
     }
+    RowTile<T, HD, BKV> kt, vt;
+    float bias_r = 0.f;
+    auto prefetch = [&](int kv0) {
+        kt.load(K, a.ldk, kv0, a.S, tid);
+        vt.load(V, a.ldv, kv0, a.S, tid);
+        if (tid < BKV) bias_r = (a.key_bias && kv0 + tid < a.S) ? a.key_bias[(long)b * a.S + kv0 + tid] * LOG2E : 0.f;
+    };
+    if (kv_beg < kv_end) prefetch(kv_beg);
     for (int kv0 = kv_beg; kv0 < kv_end; kv0 += BKV) {
         __syncthreads();
-        stage_rows<T, HD, BKV, PK>(Ks, K, a.ldk, kv0, a.S, tid);
-        if constexpr (TRD) stage_rows<T, HD, BKV, PK>(Vs, V, a.ldv, kv0, a.S, tid);
-        else stage_rows_t<T, HD, BKV, PV>(Vt, V, a.ldv, kv0, a.S, tid);
-        if (tid < BKV) bias_s[tid] = (a.key_bias && kv0 + tid < a.S) ? a.key_bias[(long)b * a.S + kv0 + tid] * LOG2E : 0.f;
+        kt.template store<PK>(Ks, tid);
+        if constexpr (TRD) vt.template store<PK>(Vs, tid);
+        else vt.template store_t<PV>(Vt, tid);
+        if (tid < BKV) bias_s[tid] = bias_r;
         __syncthreads();
+        if (kv0 + BKV < kv_end) prefetch(kv0 + BKV);
 
         f32x16 st[2];
 #pragma unroll
@@ -236,11 +258,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 psum += pv;
                 st[mb][r] = pv;
             }
-        if (a.drop_thresh != 0) {
+        if (a.drop_thresh != 0) {      // registers 2j, 2j+1 of a block are adjacent keys: one hash per pair
+            const uint32_t pbase = (uint32_t)q * s2 + (uint32_t)((kv0 + 4 * hh) >> 1);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[mb][r] *= attn_keep(a, bh_key, q, kv0 + mb * 32 + acc_row(r, lane));
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t x = attn_rand2(bh_key, pbase + (uint32_t)((mb * 32 + acc_row(2 * j, 0)) >> 1));
+                    st[mb][2 * j] = attn_keep_lo(x, a.drop_thresh) ? st[mb][2 * j] : 0.f;
+                    st[mb][2 * j + 1] = attn_keep_hi(x, a.drop_thresh) ? st[mb][2 * j + 1] : 0.f;
+                }
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
@@ -264,7 +291,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    const float inv = l_tot > 0.f ? a.drop_scale / l_tot : 0.f;      // dropout rescale folded in (1 when p = 0)
     if (q < a.T) {
         T* O = (T*)a.o + (long)b * a.bso + (long)q * a.ldo + h * HD;
 #pragma unroll
@@ -328,7 +355,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     const int qw0 = q0 + wave * 32;
     int lq = -1, lkv = 0;
     if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
-    const uint32_t bh_key = attn_bh_key(a, b, h);
+    const uint32_t bh_key = attn_bh_key(a, b, h), s2 = (uint32_t)(a.S + 1) >> 1;
 
     f32x16 acc_q[NDB];
 #pragma unroll
@@ -341,13 +368,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         kv_end = min(a.S, q0 + 128);
         if (a.window > 0 && a.window < a.T) kv_beg = max(0, q0 - a.window) / BKV * BKV;
     }
+    RowTile<T, HD, BKV> kt, vt;
+    float bias_r = 0.f;
+    auto prefetch = [&](int kv0) {
+        kt.load(K, a.ldk, kv0, a.S, tid);
+        vt.load(V, a.ldv, kv0, a.S, tid);
+        if (tid < BKV) bias_r = (a.key_bias && kv0 + tid < a.S) ? a.key_bias[(long)b * a.S + kv0 + tid] * LOG2E : 0.f;
+    };
+    if (kv_beg < kv_end) prefetch(kv_beg);
     for (int kv0 = kv_beg; kv0 < kv_end; kv0 += BKV) {
         __syncthreads();
-        stage_rows<T, HD, BKV, PK>(Ks, K, a.ldk, kv0, a.S, tid);
-        stage_rows<T, HD, BKV, PK>(Vs, V, a.ldv, kv0, a.S, tid);
-        if constexpr (!TRD) stage_rows_t<T, HD, BKV, PV>(Kt, K, a.ldk, kv0, a.S, tid);
-        if (tid < BKV) bias_s[tid] = (a.key_bias && kv0 + tid < a.S) ? a.key_bias[(long)b * a.S + kv0 + tid] * LOG2E : 0.f;
+        kt.template store<PK>(Ks, tid);
+        vt.template store<PK>(Vs, tid);
+        if constexpr (!TRD) kt.template store_t<PV>(Kt, tid);
+        if (tid < BKV) bias_s[tid] = bias_r;
         __syncthreads();
+        if (kv0 + BKV < kv_end) prefetch(kv0 + BKV);
         const bool full = (kv0 + BKV <= a.S) && (qw0 + 32 <= a.T) && lq < 0 &&
                           (!a.causal || (kv0 + BKV - 1 <= qw0 && (!win_on || kv0 >= qw0 + 31 - a.window)));
 #pragma unroll
@@ -375,11 +411,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                     if (!attn_visible(a, q, kv0 + mb * 32 + acc_row(r, lane), lq, lkv)) st[r] = 0.f;
             }
             if (drop) {
+                const uint32_t pbase = (uint32_t)q * s2 + (uint32_t)((kv0 + mb * 32 + 4 * hh) >> 1);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dp[r] *= attn_keep(a, bh_key, q, kv0 + mb * 32 + acc_row(r, lane));
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t x = attn_rand2(bh_key, pbase + (uint32_t)(acc_row(2 * j, 0) >> 1));
+                    dp[2 * j] = attn_keep_lo(x, a.drop_thresh) ? dp[2 * j] : 0.f;
+                    dp[2 * j + 1] = attn_keep_hi(x, a.drop_thresh) ? dp[2 * j + 1] : 0.f;
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = st[r] * (dp[r] - dl);     // dS^T
+            for (int r = 0; r < 16; ++r) st[r] = st[r] * fmaf(dp[r], a.drop_scale, -dl);     // dS^T = P o (M o dP / (1-p) - delta)
 #pragma unroll
             for (int s = 0; s < NFR; ++s) {
                 const F sf = acc_to_frag<T>(st, s);
@@ -439,7 +480,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int kw0 = k0 + wave * 32;
     int lq = -1, lkv = 0;
     if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
-    const uint32_t bh_key = attn_bh_key(a, b, h);
+    const uint32_t bh_key = attn_bh_key(a, b, h), s2 = (uint32_t)(a.S + 1) >> 1;
+    const uint32_t khalf = (uint32_t)key >> 1, kshift = (key & 1) * 16;
 
     f32x16 acc_k[NDB], acc_v[NDB];
 #pragma unroll
@@ -453,19 +495,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         if (a.window > 0 && a.window < a.T) q_end = min(a.T, k0 + 128 + a.window);
     }
     const long sbase = ((long)b * a.H + h) * a.T;
+    RowTile<T, HD, BQ> qt, dt;
+    float lse_r = 0.f, del_r = 0.f;
+    auto prefetch = [&](int q0) {
+        qt.load(Q, a.ldq, q0, a.T, tid);
+        dt.load(DO, a.lddo, q0, a.T, tid);
+        if (tid < BQ) {
+            lse_r = q0 + tid < a.T ? a.lse[sbase + q0 + tid] * LOG2E : 0.f;
+            del_r = q0 + tid < a.T ? a.delta[sbase + q0 + tid] : 0.f;
+        }
+    };
+    if (q_beg < q_end) prefetch(q_beg);
     for (int q0 = q_beg; q0 < q_end; q0 += BQ) {
         __syncthreads();
-        stage_rows<T, HD, BQ, PK>(Qs, Q, a.ldq, q0, a.T, tid);
-        stage_rows<T, HD, BQ, PK>(Ds, DO, a.lddo, q0, a.T, tid);
+        qt.template store<PK>(Qs, tid);
+        dt.template store<PK>(Ds, tid);
         if constexpr (!TRD) {
-            stage_rows_t<T, HD, BQ, PT>(Qt, Q, a.ldq, q0, a.T, tid);
-            stage_rows_t<T, HD, BQ, PT>(Dt, DO, a.lddo, q0, a.T, tid);
+            qt.template store_t<PT>(Qt, tid);
+            dt.template store_t<PT>(Dt, tid);
         }
-        if (tid < BQ) {
-            lse_s[tid] = q0 + tid < a.T ? a.lse[sbase + q0 + tid] * LOG2E : 0.f;
-            del_s[tid] = q0 + tid < a.T ? a.delta[sbase + q0 + tid] : 0.f;
-        }
+        if (tid < BQ) { lse_s[tid] = lse_r; del_s[tid] = del_r; }
         __syncthreads();
+        if (q0 + BQ < q_end) prefetch(q0 + BQ);
         f32x16 st, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
@@ -503,9 +554,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
                     const int r = 4 * g + e, qq = q0 + 8 * g + 4 * hh + e;
                     float pv = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, kb2) - l4[e]);
                     if (!full && !attn_visible(a, qq, key, lq, lkv)) pv = 0.f;
-                    const float keep = drop ? attn_keep(a, bh_key, qq, key) : 1.f;
-                    pd[r] = pv * keep;
-                    st[r] = pv * (dp[r] * keep - d4[e]);    // dS = P o (M o dP - delta)
+                    // this lane's key is one half of the pair hashed for (qq, key >> 1)
+                    const bool keep = !drop || (attn_rand2(bh_key, (uint32_t)qq * s2 + khalf) >> kshift & 0xffffu) >= a.drop_thresh;
+                    pd[r] = keep ? pv : 0.f;                 // rescaled by 1/(1-p) in the epilogue
+                    st[r] = pv * (keep ? fmaf(dp[r], a.drop_scale, -d4[e]) : -d4[e]);    // dS = P o (M o dP / (1-p) - delta)
                 }
             }
         }
@@ -531,7 +583,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
             if (kk >= a.S) continue;
             const int col = h * HD + d * 32 + (lane & 31);
             ((T*)a.dk)[(long)b * a.bsdk + (long)kk * a.lddk + col] = from_f32<T>(acc_k[d][r] * a.scale);
-            ((T*)a.dv)[(long)b * a.bsdv + (long)kk * a.lddv + col] = from_f32<T>(acc_v[d][r]);
+            ((T*)a.dv)[(long)b * a.bsdv + (long)kk * a.lddv + col] = from_f32<T>(acc_v[d][r] * a.drop_scale);
         }
 }
 
@@ -558,7 +610,7 @@ int fill_common(AttnArgs& a, int B, int H, int T, int S, int hd, float dropout_p
     if ((blk_lq == nullptr) != (blk_lkv == nullptr)) return OMR_ERR_ARG;
     a.B = B; a.H = H; a.T = T; a.S = S; a.scale = 1.0f / sqrtf((float)hd); a.causal = causal; a.window = window;
     a.key_bias = key_bias; a.blk_lq = blk_lq; a.blk_lkv = blk_lkv;
-    a.drop_thresh = (uint32_t)((double)dropout_p * 4294967296.0);
+    a.drop_thresh = (uint32_t)((double)dropout_p * 65536.0 + 0.5);      // 16-bit threshold (attn_rand2); 0 = dropout off
     a.drop_scale = 1.f / (1.f - dropout_p);
     a.seed = seed;
     return OMR_OK;
