@@ -136,8 +136,9 @@ __device__ __forceinline__ uint32_t attn_rand2(uint32_t bh_key, uint32_t pair_id
     x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ bool attn_keep_lo(uint32_t x, uint32_t thr16) { return (x & 0xffffu) >= thr16; }
-__device__ __forceinline__ bool attn_keep_hi(uint32_t x, uint32_t thr16) { return (x >> 16) >= thr16; }
+// thr32 = threshold << 16.  High half: (x >> 16) >= t  <=>  x >= t << 16; low half: shift it up first.
+__device__ __forceinline__ bool attn_keep_lo(uint32_t x, uint32_t thr32) { return (x << 16) >= thr32; }
+__device__ __forceinline__ bool attn_keep_hi(uint32_t x, uint32_t thr32) { return x >= thr32; }
 
 // ------------------------------------------------------------------------------------------------
 // Forward.  grid = (ceil(T/128), H, B); wave w owns query rows q0 + 32w .. +31; KV tiles of 64 keys.
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         qf[ks] = q < a.T ? *reinterpret_cast<const F*>(Q + (long)q * a.ldq + ks * KS + hh * VEC) : frag_zero<T>();
     int lq = -1, lkv = 0;
     if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
-    const uint32_t bh_key = attn_bh_key(a, b, h), s2 = (uint32_t)(a.S + 1) >> 1;
+    const uint32_t bh_key = attn_bh_key(a, b, h), s2 = (uint32_t)(a.S + 1) >> 1, thr32 = a.drop_thresh << 16;
 
     f32x16 acc_o[NDB];
 #pragma unroll
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const uint32_t x = attn_rand2(bh_key, pbase + (uint32_t)((mb * 32 + acc_row(2 * j, 0)) >> 1));
-                    st[mb][2 * j] = attn_keep_lo(x, a.drop_thresh) ? st[mb][2 * j] : 0.f;
-                    st[mb][2 * j + 1] = attn_keep_hi(x, a.drop_thresh) ? st[mb][2 * j + 1] : 0.f;
+                    st[mb][2 * j] = attn_keep_lo(x, thr32) ? st[mb][2 * j] : 0.f;
+                    st[mb][2 * j + 1] = attn_keep_hi(x, thr32) ? st[mb][2 * j + 1] : 0.f;
                 }
         }
         l_run = l_run * alpha + psum;
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     const int qw0 = q0 + wave * 32;
     int lq = -1, lkv = 0;
     if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
-    const uint32_t bh_key = attn_bh_key(a, b, h), s2 = (uint32_t)(a.S + 1) >> 1;
+    const uint32_t bh_key = attn_bh_key(a, b, h), s2 = (uint32_t)(a.S + 1) >> 1, thr32 = a.drop_thresh << 16;
 
     f32x16 acc_q[NDB];
 #pragma unroll
@@ -415,8 +416,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const uint32_t x = attn_rand2(bh_key, pbase + (uint32_t)(acc_row(2 * j, 0) >> 1));
-                    dp[2 * j] = attn_keep_lo(x, a.drop_thresh) ? dp[2 * j] : 0.f;
-                    dp[2 * j + 1] = attn_keep_hi(x, a.drop_thresh) ? dp[2 * j + 1] : 0.f;
+                    dp[2 * j] = attn_keep_lo(x, thr32) ? dp[2 * j] : 0.f;
+                    dp[2 * j + 1] = attn_keep_hi(x, thr32) ? dp[2 * j + 1] : 0.f;
                 }
             }
 #pragma unroll
@@ -446,10 +447,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 // on the register axis:  S = Q K^T ; P = exp(S - lse) ; dP = dO V^T ; dS = P o (M o dP - delta)
 //   dV += (M o P)^T dO      dK += dS^T Q        (A operand straight from accumulator registers)
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     typedef typename Frag<T>::type F;
     constexpr int VEC = ACfg<T>::VEC, NFR = ACfg<T>::NFR, KS = KStep<T>::value;
-    constexpr int NKS = HD / KS, NDB = HD / 32, BQ = 32;
+    constexpr int NKS = HD / KS, NDB = HD / 32, BQ = 64;
     constexpr int PK = HD + VEC;
     constexpr int PT = BQ + 4;   // transposed tiles [d][q]
     __shared__ __attribute__((aligned(16))) T Qs[BQ * PK];
@@ -480,8 +481,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int kw0 = k0 + wave * 32;
     int lq = -1, lkv = 0;
     if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
-    const uint32_t bh_key = attn_bh_key(a, b, h), s2 = (uint32_t)(a.S + 1) >> 1;
-    const uint32_t khalf = (uint32_t)key >> 1, kshift = (key & 1) * 16;
+    const uint32_t bh_key = attn_bh_key(a, b, h), s2 = (uint32_t)(a.S + 1) >> 1, thr32 = a.drop_thresh << 16;
+    const uint32_t khalf = (uint32_t)key >> 1, kup = (key & 1) ? 0u : 16u;   // shift that moves this key's 16 random bits to the top
 
     f32x16 acc_k[NDB], acc_v[NDB];
 #pragma unroll
@@ -517,60 +518,76 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         if (tid < BQ) { lse_s[tid] = lse_r; del_s[tid] = del_r; }
         __syncthreads();
         if (q0 + BQ < q_end) prefetch(q0 + BQ);
-        f32x16 st, dp;
+#pragma unroll 1
+        for (int mb = 0; mb < BQ / 32; ++mb) {      // not unrolled: two 32-query blocks in flight would halve the occupancy
+            const int qb = q0 + mb * 32;
+            if (qb >= q_end) break;                                     // block-uniform
+            f32x16 st, dp;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const F qf = *reinterpret_cast<const F*>(&Qs[(lane & 31) * PK + ks * KS + hh * VEC]);
-            mma32(st, qf, kf[ks]);
-            const F df = *reinterpret_cast<const F*>(&Ds[(lane & 31) * PK + ks * KS + hh * VEC]);
-            mma32(dp, df, vf[ks]);
-        }
-        f32x16 pd;  // dropped probabilities (for dV)
-        const bool full = (kw0 + 32 <= a.S) && (q0 + BQ <= a.T) && lq < 0 &&
-                          (!a.causal || (kw0 + 31 <= q0 && (!win_on || kw0 >= q0 + BQ - 1 - a.window)));
-        // one fused pass per element (few live registers); the wave-uniform `plain` branch carries no mask / dropout code
-        if (full && !drop) {
+            for (int ks = 0; ks < NKS; ++ks) {
+                const F qf = *reinterpret_cast<const F*>(&Qs[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
+                mma32(st, qf, kf[ks]);
+                const F df = *reinterpret_cast<const F*>(&Ds[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
+                mma32(dp, df, vf[ks]);
+            }
+            f32x16 pd;  // dropped probabilities (for dV)
+            const bool full = (kw0 + 32 <= a.S) && (qb + 32 <= a.T) && lq < 0 &&
+                              (!a.causal || (kw0 + 31 <= qb && (!win_on || kw0 >= qb + 31 - a.window)));
+            // one fused pass per element (few live registers); the wave-uniform `plain` branch carries no mask / dropout code
+            if (full && !drop) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lse_s[8 * g + 4 * hh]);   // already * log2 e
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(&del_s[8 * g + 4 * hh]);
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lse_s[mb * 32 + 8 * g + 4 * hh]);   // already * log2 e
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(&del_s[mb * 32 + 8 * g + 4 * hh]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, kb2) - l4[e]);
-                    pd[r] = pv;
-                    st[r] = pv * (dp[r] - d4[e]);    // dS
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, kb2) - l4[e]);
+                        pd[r] = pv;
+                        st[r] = pv * (dp[r] - d4[e]);    // dS
+                    }
+                }
+            } else {
+                // The hash of (query, key >> 1) serves both lanes of a key pair (lane, lane ^ 1): each lane computes it for
+                // every other query register and the two swap through a DPP quad permute.
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lse_s[mb * 32 + 8 * g + 4 * hh]);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(&del_s[mb * 32 + 8 * g + 4 * hh]);
+                    uint32_t xr[4] = {0u, 0u, 0u, 0u};
+                    if (drop) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const uint32_t x = attn_rand2(bh_key, (uint32_t)(qb + 8 * g + 4 * hh + 2 * j + (lane & 1)) * s2 + khalf);
+                            const uint32_t y = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                            xr[2 * j] = (lane & 1) ? y : x;
+                            xr[2 * j + 1] = (lane & 1) ? x : y;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e, qq = qb + 8 * g + 4 * hh + e;
+                        float pv = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, kb2) - l4[e]);
+                        if (!full && !attn_visible(a, qq, key, lq, lkv)) pv = 0.f;
+                        const bool keep = !drop || (xr[e] << kup) >= thr32;
+                        pd[r] = keep ? pv : 0.f;                 // rescaled by 1/(1-p) in the epilogue
+                        st[r] = pv * (keep ? fmaf(dp[r], a.drop_scale, -d4[e]) : -d4[e]);    // dS = P o (M o dP / (1-p) - delta)
+                    }
                 }
             }
-        } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lse_s[8 * g + 4 * hh]);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(&del_s[8 * g + 4 * hh]);
+            for (int s = 0; s < NFR; ++s) {
+                const F pf = acc_to_frag<T>(pd, s);
+                const F sf = acc_to_frag<T>(st, s);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e, qq = q0 + 8 * g + 4 * hh + e;
-                    float pv = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, kb2) - l4[e]);
-                    if (!full && !attn_visible(a, qq, key, lq, lkv)) pv = 0.f;
-                    // this lane's key is one half of the pair hashed for (qq, key >> 1)
-                    const bool keep = !drop || (attn_rand2(bh_key, (uint32_t)qq * s2 + khalf) >> kshift & 0xffffu) >= a.drop_thresh;
-                    pd[r] = keep ? pv : 0.f;                 // rescaled by 1/(1-p) in the epilogue
-                    st[r] = pv * (keep ? fmaf(dp[r], a.drop_scale, -d4[e]) : -d4[e]);    // dS = P o (M o dP / (1-p) - delta)
+                for (int d = 0; d < NDB; ++d) {
+                    const F dtf = kperm_frag<T>(Ds, PK, Dt, PT, mb * 32, s, d * 32, lane);
+                    mma32(acc_v[d], pf, dtf);
+                    const F qtf = kperm_frag<T>(Qs, PK, Qt, PT, mb * 32, s, d * 32, lane);
+                    mma32(acc_k[d], sf, qtf);
                 }
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < NFR; ++s) {
-            const F pf = acc_to_frag<T>(pd, s);
-            const F sf = acc_to_frag<T>(st, s);
-#pragma unroll
-            for (int d = 0; d < NDB; ++d) {
-                const F dtf = kperm_frag<T>(Ds, PK, Dt, PT, 0, s, d * 32, lane);
-                mma32(acc_v[d], pf, dtf);
-                const F qtf = kperm_frag<T>(Qs, PK, Qt, PT, 0, s, d * 32, lane);
-                mma32(acc_k[d], sf, qtf);
             }
         }
     }
