@@ -19,6 +19,7 @@
 #include "omr_hip.h"
 
 #include "conv_wgrad.h"
+#include "dma_common.h"
 
 // Ablation switches for bring-up (make CXXFLAGS+=-DOMR_WGRAD_DEBUG; OMR_WGRAD_DBG=bits at run time): 1 dummy sources,
 // 2 no MFMA loop, 4 no bias sums, 8 no DMA, 16 no barrier, 32 no final accumulation.  Never compiled into the product.
@@ -29,30 +30,13 @@
 #define DBG(bit) false
 #endif
 
-#pragma clang diagnostic ignored "-Winline-asm"
-
 namespace {
 
 constexpr int TW = 32;   // output pixels per tile row = two MFMA k-steps
 constexpr int NUM_CU = 256;
 typedef __attribute__((address_space(3))) bf16x4 LdsV4;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 __device__ uint4 g_zero16;   // 16 zero bytes in global memory: the DMA source of every out-of-image / out-of-range chunk
-
-// One wave instruction: lane i fetches 16 bytes from its own global address into LDS byte address lds_wave_base + 16 i.
-__device__ __forceinline__ void dma16(const void* gptr, unsigned lds_wave_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :: "v"(gptr), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base)) : "memory", "m0");
-}
-// Wait until at most PENDING of this wave's DMA instructions are still in flight (they complete in order), make this
-// wave's LDS writes visible, then the workgroup barrier.  The compiler does not track the asm DMA, hence the explicit
-// count; the "memory" clobber keeps LDS accesses from moving across.
-template <int PENDING> __device__ __forceinline__ void dma_wait_barrier() {
-    static_assert(PENDING >= 0 && PENDING < 64, "vmcnt is a 6-bit counter");
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(PENDING) : "memory");
-}
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Placement of 16-byte chunk c of tile pixel `pix` inside a dense [pixel][CB] LDS tile.  Each lane of the DMA chooses its
 // own global source, so bank conflicts are removed by permuting where a chunk lands instead of padding rows:
@@ -139,11 +123,12 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
     typedef TileDma<CBC, NPX, NTHR> DX_;
     constexpr int YS = DY_::ELEMS, BUF = YS + DX_::ELEMS;              // elements per ring slot
     constexpr int DMA_PER_TILE = DY_::ROUNDS + DX_::ROUNDS;
+    constexpr int KUNROLL = NPY / 16 / WK <= 2 ? 2 : 1;     // k-steps per wave per tile: unroll the short loops only (register budget)
     static_assert(WK >= 1 && WN * WC * WK == NW && NSTAGE >= 2, "wave split / ring depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* ring = reinterpret_cast<bf16*>(smem_raw);                      // [NSTAGE][BUF]
     float* sstat = reinterpret_cast<float*>(ring + NSTAGE * BUF + 512);  // after the 1 KB DMA scratch; NORM: [mean | rstd][CBC] of the current image
-    const unsigned ring_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+    const unsigned ring_addr = lds_address(smem_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave / (WN * WC), wn = (wave % (WN * WC)) / WC, wc = wave % WC;
@@ -237,7 +222,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
             const int ch = tid % CBN;
             for (int pix = tid / CBN; pix < NPY; pix += NPH) bsum += (float)Ys[PY::off(pix, ch)];
         }
-#pragma unroll(NPY / 16 / WK <= 2 ? 2 : 1)
+#pragma unroll KUNROLL
         for (int k0 = wk * 16; k0 < (DBG(2) ? 0 : NPY); k0 += WK * 16) {
             const int pk = k0 + 8 * hh + q;                  // pixels pk..pk+3 (u = 0) and pk+4..pk+7 (u = 1), same tile row
             const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(Ys + PY::off(pk, cha)));
@@ -255,7 +240,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
         }
         cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing dummy DMAs must not outlive the workgroup's LDS
+    dma_drain();        // the trailing dummy DMAs must not outlive the workgroup's LDS
     // Device-scope float atomics execute at the memory side and serialise per address (~3 ns each on one cache line), so
     // every partial sum is first combined inside the workgroup through LDS (the ring is dead by now).
     float* red = reinterpret_cast<float*>(smem_raw);        // [NW][16][64]

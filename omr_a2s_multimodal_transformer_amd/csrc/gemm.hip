@@ -21,14 +21,26 @@
 #include "omr_common.h"
 #include "omr_hip.h"
 
+#include "gemm_args.h"
+
 namespace {
 
-struct GemmArgs {
-    const void* A; const void* B; void* C; const float* bias;
-    int M, N, K; long lda, ldb, ldc;
-    int relu, accum, atomic, ksplit_len;
-    float* colsum_a;   // transA only: colsum_a[m] += sum_k A[k][m] (bias gradient of a linear layer), fused into the dW GEMM
-};
+// Tile of a workgroup.  Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share an L2), so the linear
+// tile order (split-major, then M tile, N tile fastest) is cut into chunks of `chunk` consecutive tiles and chunk c goes
+// to XCD label c % 8: the N tiles that re-read one A panel -- or, with split-K, all tiles that re-read one K slice of both
+// operands -- hit the same L2 instead of pulling the panel over the fabric once per XCD.  Pure speed: any placement is
+// correct.  The grid is padded to whole rounds of 8 chunks; padded workgroups exit.
+struct TileId { int m, n, split; bool valid; };
+__device__ __forceinline__ TileId tile_of_block(const GemmArgs& g) {
+    const int L = blockIdx.x, slot = L >> 3;
+    const long J = ((long)(slot / g.chunk) * 8 + (L & 7)) * g.chunk + slot % g.chunk;
+    TileId t;
+    t.valid = J < g.total;
+    t.n = (int)(J % g.nt);
+    t.m = (int)((J / g.nt) % g.mt);
+    t.split = (int)(J / ((long)g.nt * g.mt));
+    return t;
+}
 
 constexpr int BM = 128, BN = 128;
 
@@ -138,8 +150,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.ksplit_len;
+    const TileId tile = tile_of_block(g);
+    if (!tile.valid) return;
+    const int m0 = tile.m * BM, n0 = tile.n * BN;
+    const int kbeg = tile.split * g.ksplit_len;
     const int kend = min(g.K, kbeg + g.ksplit_len);
     const T* A = (const T*)g.A;
     const T* B = (const T*)g.B;
@@ -157,7 +171,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     float cs[Cfg::VEC];
 #pragma unroll
     for (int e = 0; e < Cfg::VEC; ++e) cs[e] = 0.f;
-    const bool do_cs = TA && g.colsum_a != nullptr && blockIdx.x == 0;
+    const bool do_cs = TA && g.colsum_a != nullptr && tile.n == 0;
     sa.load(A, g.lda, m0, g.M, kbeg, kend, tid);
     sb.load(B, g.ldb, n0, g.N, kbeg, kend, tid);
     if (do_cs) sa.add_colsum(cs);
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int col = n0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + hsel;
-                bv[r] = (g.bias != nullptr && blockIdx.z == 0 && col < g.N) ? g.bias[col] : 0.f;
+                bv[r] = (g.bias != nullptr && tile.split == 0 && col < g.N) ? g.bias[col] : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + col_l;
             if (col >= g.N) continue;
-            const float bv = (g.bias != nullptr && blockIdx.z == 0) ? g.bias[col] : 0.f;
+            const float bv = (g.bias != nullptr && tile.split == 0) ? g.bias[col] : 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -284,8 +298,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
-template <typename T, typename TC> int launch(const GemmArgs& g, int ta, int tb, int splits, hipStream_t s) {
-    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), splits), block(256);
+template <typename T, typename TC> int launch(GemmArgs g, int ta, int tb, int splits, hipStream_t s) {
+    g.nt = cdiv(g.N, BN); g.mt = cdiv(g.M, BM);
+    g.total = g.nt * g.mt * splits;
+    g.chunk = splits > 1 ? g.nt * g.mt : g.nt;
+    const int nchunks = g.total / g.chunk;
+    dim3 grid((unsigned)(cdiv(nchunks, 8) * 8 * g.chunk)), block(256);
     if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, TC, false, false>), grid, block, 0, s, g);
     else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, TC, false, true>), grid, block, 0, s, g);
     else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, TC, true, false>), grid, block, 0, s, g);
