@@ -247,62 +247,90 @@ template <typename T, int TH1, int TH2> int launch_wgrad(const WgradArgs& a, hip
 }
 
 // ------------------------------------------------------------------------------------------------
-// First layer: Cin = 1 -> COUT (<= 32) with ReLU.  One thread per output pixel; K = 9, HBM-bound.
+// First layer: Cin = 1 -> COUT (<= 32) with ReLU; K = 9, HBM-bound (2 B in, 2 COUT B out per pixel).
+// Thread = one image column: it walks down RC rows of one image with a 3x3 register window (3 new 2-byte loads per
+// pixel, the next row's already in flight while this row's 9 COUT FMAs run) and writes its pixel's COUT channels as 16-byte
+// stores.  Weights sit in LDS tap-major and are read as broadcast float4s; ~50 VGPRs keep 8 waves per SIMD resident.
 template <typename T, int COUT>
 __global__ __launch_bounds__(256) void conv1_direct_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, int B,
-                                                           int H, int Wd, int relu) {
-    __shared__ float ws[COUT * 9 + COUT];
-    for (int i = threadIdx.x; i < COUT * 9; i += blockDim.x) ws[i] = to_f32(w[i]);
-    for (int i = threadIdx.x; i < COUT; i += blockDim.x) ws[COUT * 9 + i] = bias ? bias[i] : 0.f;
+                                                           int H, int Wd, int relu, int RC) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N;
+    __shared__ __attribute__((aligned(16))) float ws[10 * COUT];              // [tap][COUT] then bias
+    for (int i = threadIdx.x; i < COUT * 9; i += blockDim.x) ws[(i % 9) * COUT + i / 9] = to_f32(w[i]);
+    for (int i = threadIdx.x; i < COUT; i += blockDim.x) ws[9 * COUT + i] = bias ? bias[i] : 0.f;
     __syncthreads();
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;      // image column; blockIdx.y walks image rows (32-bit math only)
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Wd) return;
-    const int rows = B * H;
-    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
-        const int i = row % H;
-        float in[9];
+    const int chunks = cdiv(H, RC);
+    const int b = blockIdx.y / chunks, r0 = (blockIdx.y % chunks) * RC, r1 = min(H, r0 + RC);
+    const T* xb = x + (long)b * H * Wd;
+    T* yb = y + (long)b * H * Wd * COUT;
+    auto load_row = [&](int r, float (&row)[3]) {
+        row[0] = row[1] = row[2] = 0.f;
+        if (r >= 0 && r < H) {
+            const T* xr = xb + (long)r * Wd + j;
+            row[1] = to_f32(xr[0]);
+            if (j > 0) row[0] = to_f32(xr[-1]);
+            if (j + 1 < Wd) row[2] = to_f32(xr[1]);
+        }
+    };
+    float win[3][3], nxt[3];
+    load_row(r0 - 1, win[0]);
+    load_row(r0, win[1]);
+    load_row(r0 + 1, win[2]);
+    for (int r = r0; r < r1; ++r) {
+        load_row(r + 2, nxt);                                   // in flight behind this row's math
+        asm volatile("" ::: "memory");                          // re-read the weights from LDS every row: hoisting all 10 COUT of them costs the occupancy
+        float acc[COUT];
+#pragma unroll
+        for (int n = 0; n < COUT; n += 4) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(&ws[9 * COUT + n]);
+            acc[n] = bv[0]; acc[n + 1] = bv[1]; acc[n + 2] = bv[2]; acc[n + 3] = bv[3];
+        }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int ii = i + t / 3 - 1, jj = j + t % 3 - 1;
-            in[t] = (ii >= 0 && ii < H && jj >= 0 && jj < Wd) ? to_f32(x[(long)(row + t / 3 - 1) * Wd + jj]) : 0.f;
-        }
-        typedef typename Frag<T>::type F;
-        F* dst = reinterpret_cast<F*>(y + ((long)row * Wd + j) * COUT);
+            const float xv = win[t / 3][t % 3];
 #pragma unroll
-        for (int v = 0; v < COUT / Frag<T>::N; ++v) {
+            for (int n = 0; n < COUT; n += 4) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(&ws[t * COUT + n]);
+                acc[n] += wv[0] * xv; acc[n + 1] += wv[1] * xv; acc[n + 2] += wv[2] * xv; acc[n + 3] += wv[3] * xv;
+            }
+        }
+        F* dst = reinterpret_cast<F*>(yb + ((long)r * Wd + j) * COUT);
+#pragma unroll
+        for (int v = 0; v < COUT / VEC; ++v) {
             F f;
 #pragma unroll
-            for (int e = 0; e < Frag<T>::N; ++e) {
-                const int n = v * Frag<T>::N + e;
-                float s = ws[COUT * 9 + n];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) s += ws[n * 9 + t] * in[t];
-                f[e] = from_f32<T>(relu ? fmaxf(s, 0.f) : s);
-            }
+            for (int e = 0; e < VEC; ++e) f[e] = from_f32<T>(relu ? fmaxf(acc[v * VEC + e], 0.f) : acc[v * VEC + e]);
             dst[v] = f;
         }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { win[0][c] = win[1][c]; win[1][c] = win[2][c]; win[2][c] = nxt[c]; }
     }
 }
-// dW[n][tap] += sum_p dY[p][n] x[p + tap]; db[n] += sum_p dY[p][n].  Thread = (pixel column, tap row kh): it keeps
-// COUT x 3 partial sums in registers while walking image rows; 16-byte dY loads; LDS then global fp32 atomics at the end.
+// dW[n][tap] += sum_p dY[p][n] x[p + tap]; db[n] += sum_p dY[p][n].  Workgroup = 3 waves x 64 image columns, wave = tap
+// row kh: a thread keeps COUT x 3 partial sums in registers while walking image rows (16-byte dY loads, the next row's in
+// flight behind this row's FMAs).  All lanes of a wave then hold sums for the SAME weights, so they fold with wave shuffles;
+// one lane per wave adds to LDS, one global fp32 atomic per weight per workgroup.
 template <typename T, int COUT>
-__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db, int B, int H, int Wd) {
+__global__ __launch_bounds__(192) void conv1_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db, int B, int H, int Wd) {
     typedef typename Frag<T>::type F;
     constexpr int VEC = Frag<T>::N, NV = COUT / VEC;
     __shared__ float red[COUT * 10];
     for (int i = threadIdx.x; i < COUT * 10; i += blockDim.x) red[i] = 0.f;
     __syncthreads();
-    const int kh = threadIdx.x % 3, pl = threadIdx.x / 3;
-    const int j = blockIdx.x * 85 + pl;
+    const int kh = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 64 + lane;
     float acc[3][COUT], accb[COUT];
 #pragma unroll
     for (int n = 0; n < COUT; ++n) { acc[0][n] = acc[1][n] = acc[2][n] = 0.f; accb[n] = 0.f; }
-    if (threadIdx.x < 255 && j < Wd) {
+    if (j < Wd) {
         const int rows = B * H;
-        for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        auto load = [&](int row, float (&xv)[3], F (&gv)[NV]) {
             const int i = row % H;
             const int yy = i + kh - 1;
-            float xv[3] = {0.f, 0.f, 0.f};
+            xv[0] = xv[1] = xv[2] = 0.f;
             if (yy >= 0 && yy < H) {
                 const T* xr = x + (long)(row + kh - 1) * Wd;
                 xv[0] = j > 0 ? to_f32(xr[j - 1]) : 0.f;
@@ -311,22 +339,41 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const T* __restrict__ 
             }
             const F* gp = reinterpret_cast<const F*>(dy + ((long)row * Wd + j) * COUT);
 #pragma unroll
+            for (int v = 0; v < NV; ++v) gv[v] = gp[v];
+        };
+        float xv[3], xn[3] = {0.f, 0.f, 0.f};
+        F gv[NV], gn[NV];
+        if ((int)blockIdx.y < rows) load(blockIdx.y, xv, gv);
+        for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+            const int next = row + gridDim.y;
+            if (next < rows) load(next, xn, gn);                 // the next row's loads fly behind this row's FMAs
+#pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const F gv = gp[v];
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    const float g = to_f32(gv[e]);
+                    const float g = to_f32(gv[v][e]);
                     const int n = v * VEC + e;
                     acc[0][n] += g * xv[0]; acc[1][n] += g * xv[1]; acc[2][n] += g * xv[2];
                     if (kh == 1) accb[n] += g;
                 }
             }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) xv[c] = xn[c];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) gv[v] = gn[v];
         }
+    }
+    // columns beyond the image hold zeros: every lane takes part in the wave reductions
 #pragma unroll
-        for (int n = 0; n < COUT; ++n) {
+    for (int n = 0; n < COUT; ++n) {
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) atomicAdd(&red[n * 9 + kh * 3 + kw], acc[kw][n]);
-            if (kh == 1) atomicAdd(&red[COUT * 9 + n], accb[n]);
+        for (int kw = 0; kw < 3; ++kw) {
+            const float v = wave_sum(acc[kw][n]);
+            if (lane == 0) red[n * 9 + kh * 3 + kw] = v;        // (n, kh, kw) has exactly one writer
+        }
+        if (kh == 1) {
+            const float v = wave_sum(accb[n]);
+            if (lane == 0) red[COUT * 9 + n] = v;
         }
     }
     __syncthreads();
@@ -502,11 +549,11 @@ extern "C" int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const fl
     if (CIN == 1) {
         if (drop_p > 0.f || stat_mode) return OMR_ERR_UNSUPPORTED;
         if (dil_h != 1 || dil_w != 1 || stride_h != 1 || stride_w != 1 || in_mean || out_mask || Ho != H || Wo != W) return OMR_ERR_UNSUPPORTED;
-        int gy1 = B * H; if (gy1 > 1024) gy1 = 1024;
-        dim3 g1(cdiv(W, 256), gy1);
+        const int RC = 32;                                   // rows per workgroup: 2 halo rows per 32 re-read
+        dim3 g1(cdiv(W, 256), B * cdiv(H, RC));
         DISPATCH_T(dtype, {
-            if (COUT == 16) hipLaunchKernelGGL((conv1_direct_kernel<T, 16>), g1, 256, 0, s, (const T*)x, (const T*)w, bias, (T*)y, B, H, W, relu);
-            else if (COUT == 32) hipLaunchKernelGGL((conv1_direct_kernel<T, 32>), g1, 256, 0, s, (const T*)x, (const T*)w, bias, (T*)y, B, H, W, relu);
+            if (COUT == 16) hipLaunchKernelGGL((conv1_direct_kernel<T, 16>), g1, 256, 0, s, (const T*)x, (const T*)w, bias, (T*)y, B, H, W, relu, RC);
+            else if (COUT == 32) hipLaunchKernelGGL((conv1_direct_kernel<T, 32>), g1, 256, 0, s, (const T*)x, (const T*)w, bias, (T*)y, B, H, W, relu, RC);
             else return OMR_ERR_UNSUPPORTED;
         });
         OMR_CHECK_LAUNCH();
@@ -538,11 +585,11 @@ extern "C" int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float
     hipStream_t s = (hipStream_t)stream;
     if (CIN == 1) {
         if (stride_h != 1 || stride_w != 1 || in_mean) return OMR_ERR_UNSUPPORTED;
-        int gy = B * H; if (gy > 32) gy = 32;      // few, long-lived blocks: each ends with 10 COUT atomics onto the same five cache lines
-        dim3 grid(cdiv(W, 85), gy);
+        int gy = B * H; if (gy > 64) gy = 64;      // few, long-lived blocks: each ends with 10 COUT atomics onto the same five cache lines
+        dim3 grid(cdiv(W, 64), gy);
         DISPATCH_T(dtype, {
-            if (COUT == 16) hipLaunchKernelGGL((conv1_wgrad_kernel<T, 16>), grid, 256, 0, s, (const T*)x, (const T*)dy, dw, db, B, H, W);
-            else if (COUT == 32) hipLaunchKernelGGL((conv1_wgrad_kernel<T, 32>), grid, 256, 0, s, (const T*)x, (const T*)dy, dw, db, B, H, W);
+            if (COUT == 16) hipLaunchKernelGGL((conv1_wgrad_kernel<T, 16>), grid, 192, 0, s, (const T*)x, (const T*)dy, dw, db, B, H, W);
+            else if (COUT == 32) hipLaunchKernelGGL((conv1_wgrad_kernel<T, 32>), grid, 192, 0, s, (const T*)x, (const T*)dy, dw, db, B, H, W);
             else return OMR_ERR_UNSUPPORTED;
         });
         OMR_CHECK_LAUNCH();

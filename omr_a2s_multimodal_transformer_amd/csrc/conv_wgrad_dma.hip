@@ -127,7 +127,8 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
     static_assert(WK >= 1 && WN * WC * WK == NW && NSTAGE >= 2, "wave split / ring depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* ring = reinterpret_cast<bf16*>(smem_raw);                      // [NSTAGE][BUF]
-    float* sstat = reinterpret_cast<float*>(ring + NSTAGE * BUF + 512);  // after the 1 KB DMA scratch; NORM: [mean | rstd][CBC] of the current image
+    // after the 1 KB DMA scratch; NORM: 8 x 512-byte slots [mean | rstd][CBC], one per image the ring currently spans
+    float* sstat_base = reinterpret_cast<float*>(ring + NSTAGE * BUF + 512);
     const unsigned ring_addr = lds_address(smem_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
     iy.init(a.Wo, a.COUT, a.COUT - n0, tid);
     ix.init(a.Wr, a.CIN, a.CIN - c0, tid);
     const float inv_tpi = 1.0f / (float)tiles_per_img, inv_tw = 1.0f / (float)a.tiles_w;
+    int iss_b = -1, iss_slot = 0;      // NORM: image and statistics slot of the most recently issued tile
     auto issue = [&](int tile, int slot) {   // tile >= ntiles: a dummy issue (zeros) that keeps the in-flight count exact
         const bool live = tile < ntiles && !DBG(1);
         if (DBG(8)) return;
@@ -156,6 +158,24 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
         const bool in_y = live && oh0 + TH <= a.Ho && ow0 + TW <= a.Wo;
         const bool in_x = live && ih0 >= 0 && ih0 + IH <= a.Hr && iw0 >= 0 && iw0 + IW <= a.Wr;
         const unsigned ya = ring_addr + (unsigned)(slot * BUF) * 2u, scratch = ring_addr + (unsigned)(NSTAGE * BUF) * 2u;
+        if constexpr (NORM) {
+            // The tile's image statistics ride the same DMA queue, AHEAD of the tile's own pieces (in-order completion: landed when the tile has): on an image change (block-uniform, so every wave's
+            // instruction count stays equal) wave 0 fetches mean | rstd of this block's channels into the next 1 KB
+            // statistics slot; the other waves send zeros to the scratch.  An ordinary load here would make the compiler
+            // wait for vmcnt(0) and drain the ring once per image.
+            if (live && b != iss_b) {
+                iss_b = b;
+                iss_slot = (iss_slot + 1) & 7;
+                const int l4 = lane * 4;                       // this lane's first channel (mean) or CBC + channel (rstd)
+                const float* src = l4 < CBC ? a.mean : a.rstd;
+                const int ch = c0 + (l4 < CBC ? l4 : l4 - CBC);
+                const bool ok = l4 < 2 * CBC && ch < a.CIN;
+                if (tid >= 64) dma16(&g_zero16, scratch);        // keeps the other waves' DMA count in step
+                else if (lane < 32)                              // 512-byte slot: the upper half-wave writes nothing
+                    dma16(ok ? (const void*)(src + (long)b * a.CIN + ch) : (const void*)&g_zero16,
+                          ring_addr + (unsigned)(NSTAGE * BUF) * 2u + 1024u + (unsigned)iss_slot * 512u);
+            }
+        }
         iy.issue(DY + ((long)b * a.Ho * a.Wo + (long)th * TH * a.Wo + ow0) * a.COUT + n0, oh0, ow0, a.Ho, a.Wo, in_y, ya, scratch, tid);
         ix.issue(X + ((long)b * a.Hr * a.Wr + (long)(th * TH * SH - 1) * a.Wr + iw0) * a.CIN + c0, ih0, iw0, a.Hr, a.Wr, in_x, ya + (unsigned)YS * 2u,
                  scratch, tid);
@@ -179,7 +199,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
     int tile = blockIdx.x;
 #pragma unroll
     for (int st = 0; st < NSTAGE - 1; ++st) issue(tile + st * (int)gridDim.x, st);
-    int cur = 0, stat_b = -1;
+    int cur = 0, stat_b = -1, stat_slot = 0;
+    const float* sstat = sstat_base;
+    float rs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, nb8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // NORM, rows <= 64 B: this thread's channel statistics
     for (; tile < ntiles; tile += gridDim.x) {
         // tile `cur` has landed in every wave's share; the slot consumed in the previous iteration is free again
         if (!DBG(16)) dma_wait_barrier<(NSTAGE - 2) * DMA_PER_TILE>();
@@ -187,31 +209,44 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
         bf16* Ys = ring + cur * BUF;
         bf16* Xs = Ys + YS;
         if constexpr (NORM) {
-            // xhat = (x - mean) * rstd in place; out-of-image halo pixels stay 0 (the conv pads the NORMALISED input)
+            // xhat = x * rstd - mean * rstd in place; out-of-image halo pixels stay 0 (the conv pads the NORMALISED input).
+            // The pass walks the same (round, lane) -> chunk map as the DMA, so validity and tile coordinates come from the
+            // issuer's descriptors; with rows of <= 64 bytes a thread always meets the same 8 channels and keeps their
+            // statistics in registers (refreshed once per image).
             const int b = fdiv(tile, tiles_per_img, inv_tpi), rem = tile - b * tiles_per_img;
-            if (b != stat_b) {      // block-uniform, once per image: this plain load drains the DMA queue, which is fine here
-                if (tid < 2 * CBC) {
-                    const int ch = c0 + (tid % CBC);
-                    const float* src = tid < CBC ? a.mean : a.rstd;
-                    sstat[tid] = ch < a.CIN ? src[b * a.CIN + ch] : 0.f;
-                }
+            if (b != stat_b) {      // block-uniform: the slot was filled by the DMA that preceded this tile's own (already landed)
                 stat_b = b;
-                lds_barrier();
+                stat_slot = (stat_slot + 1) & 7;
+                sstat = sstat_base + stat_slot * 128;
+                if constexpr (CBC <= 32) {
+                    const int cf = (tid % (CBC / 8)) * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { rs8[e] = sstat[CBC + cf + e]; nb8[e] = -sstat[cf + e] * rs8[e]; }
+                }
             }
             issue(tile + (NSTAGE - 1) * (int)gridDim.x, nslot);
             const int th = fdiv(rem, a.tiles_w, inv_tw);
             const int ih0 = th * TH * SH - 1, iw0 = (rem - th * a.tiles_w) * TW * SW - 1;
-            for (int L = tid; L < DX_::NCH; L += NTHR) {
-                int pix, c;
-                PX::source(L, pix, c);
-                if (pix >= NPX) continue;
-                const int il = pix / IW, jl = pix - il * IW;
-                const int ih = ih0 + il, iw = iw0 + jl;
-                if (ih < 0 || ih >= a.Hr || iw < 0 || iw >= a.Wr || c0 + c * 8 >= a.CIN) continue;
-                bf16x8 v = *reinterpret_cast<bf16x8*>(Xs + (long)L * 8);
+            const bool in_x = ih0 >= 0 && ih0 + IH <= a.Hr && iw0 >= 0 && iw0 + IW <= a.Wr;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (bf16)(((float)v[e] - sstat[c * 8 + e]) * sstat[CBC + c * 8 + e]);
-                *reinterpret_cast<bf16x8*>(Xs + (long)L * 8) = v;
+            for (int r = 0; r < DX_::ROUNDS; ++r) {
+                if (ix.rel[r] < 0) continue;                  // pad lane / channel tail: nothing was fetched
+                if (!in_x) {
+                    const int ih = ih0 + (ix.ij[r] & 0xffff), iw = iw0 + (ix.ij[r] >> 16);
+                    if ((unsigned)ih >= (unsigned)a.Hr || (unsigned)iw >= (unsigned)a.Wr) continue;
+                }
+                bf16* px = Xs + (long)(r * NTHR + tid) * 8;
+                bf16x8 v = *reinterpret_cast<bf16x8*>(px);
+                if constexpr (CBC <= 32) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16)fmaf((float)v[e], rs8[e], nb8[e]);
+                } else {
+                    int pix, c;
+                    PX::source(r * NTHR + tid, pix, c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16)(((float)v[e] - sstat[c * 8 + e]) * sstat[CBC + c * 8 + e]);
+                }
+                *reinterpret_cast<bf16x8*>(px) = v;
             }
             lds_barrier();
         } else {
@@ -288,7 +323,7 @@ template <int CBN, int CBC, int TH, int SH, int SW, int NW, int NSTAGE, bool NOR
     a.tiles_h = cdiv(a.Ho, TH);
     constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3;
     constexpr size_t shm = (size_t)NSTAGE * (TileDma<CBN, TH * TW, NW * 64>::ELEMS + TileDma<CBC, IH * IW, NW * 64>::ELEMS) * sizeof(bf16) +
-                           1024 + (NORM ? 2 * CBC * sizeof(float) : 0);
+                           1024 + (NORM ? 8 * 512 : 0);
     static_assert(shm <= 160 * 1024, "LDS ring does not fit");
     auto kern = wgrad_dma_kernel<CBN, CBC, TH, SH, SW, NW, NSTAGE, NORM>;
     static int occ_cache = 0;            // resident blocks per CU of this instantiation: the persistent grid fills the chip once
@@ -337,6 +372,7 @@ template <int SH, int SW, bool NORM> int pick(const WgradArgs& a, hipStream_t s)
 int omr_wgrad_dma_bf16(const WgradArgs& a, hipStream_t s) {
     if (a.CIN % 8 || a.COUT % 8) return OMR_ERR_UNSUPPORTED;
     const bool norm = a.mean != nullptr;
+    if (norm && ((((uintptr_t)a.mean) | ((uintptr_t)a.rstd)) & 15)) return OMR_ERR_UNSUPPORTED;      // statistics are fetched in 16-byte pieces
     if (a.sh == 1 && a.sw == 1) return norm ? pick<1, 1, true>(a, s) : pick<1, 1, false>(a, s);
     if (a.sh == 2 && a.sw == 2) return norm ? pick<2, 2, true>(a, s) : pick<2, 2, false>(a, s);
     if (a.sh == 2 && a.sw == 1) return norm ? pick<2, 1, true>(a, s) : pick<2, 1, false>(a, s);
