@@ -57,11 +57,15 @@ int omr_instnorm_bwd_apply(int dtype, const void* dxhat, const void* x, const fl
                            int relu_mask, float relu_scale, const void* workspace, void* stream);
 int omr_instnorm_bwd(int dtype, const void* dxhat, const void* x, const float* mean, const float* rstd, void* dx, int B, long HW, int C,
                      int relu_mask, float relu_scale, void* workspace, void* stream);
-/* post-norm residual: out = LayerNorm(x + res) (eps 1e-5), torch nn/modules/transformer.py:1146-1154 */
+/* post-norm residual with the sublayer dropout fused: out = LayerNorm(dropout(x) + res) (eps 1e-5), torch
+ * nn/modules/transformer.py:1146-1154 (x = dropout1/2/3(sublayer), res = the residual stream).  drop_p = 0: plain add.
+ * The mask is omr_dropout's counter-based mask (same seed / element-index convention) and is regenerated in backward.
+ * Backward: ds = gradient of res (and of x when drop_p = 0); with drop_p > 0, dx receives the gradient of x. */
 int omr_add_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* out, float* mean,
-                          float* rstd, long M, int d, float eps, void* stream);
+                          float* rstd, long M, int d, float eps, float drop_p, unsigned long long drop_seed, void* stream);
 int omr_add_layernorm_bwd(int dtype, const void* dy, const void* x, const void* res, const float* gamma, const float* mean,
-                          const float* rstd, void* ds, float* dgamma, float* dbeta, long M, int d, void* stream);
+                          const float* rstd, void* ds, float* dgamma, float* dbeta, long M, int d, float drop_p,
+                          unsigned long long drop_seed, void* dx, void* stream);
 
 /* ---- GEMM: C[M,N] (+)= act(opA(A) . opB(B)^T + bias) ------------------------------------------------------ */
 /* aten::linear/addmm/mm of the decoder layers (torch nn/modules/transformer.py:1158-1199), 1x1 point_conv

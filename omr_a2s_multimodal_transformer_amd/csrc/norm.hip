@@ -113,12 +113,16 @@ __global__ __launch_bounds__(256) void instnorm_bwd_apply_kernel(const T* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// out = LayerNorm(x + res) * gamma + beta.  One wave per row; lane l owns the PER = d/64 CONSECUTIVE elements
+// out = LayerNorm(dropout(x) + res) * gamma + beta.  One wave per row; lane l owns the PER = d/64 CONSECUTIVE elements
 // [l*PER, (l+1)*PER) so every tensor is touched with one vector load/store per lane per row.  Saves mean and rstd.
+// The sublayer dropout that precedes every post-norm residual (torch nn/modules/transformer.py:1146-1154) is fused:
+// drop_thresh != 0 applies the counter-based mask of omr_dropout (same seed/index convention, element index row*d + c)
+// to x; the backward regenerates it.
 template <typename T, int PER>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ out, float* __restrict__ mean,
-                                                         float* __restrict__ rstd, long M, float eps) {
+                                                         float* __restrict__ rstd, long M, float eps, uint32_t drop_thresh, float drop_scale,
+                                                         uint64_t drop_seed) {
     typedef __attribute__((ext_vector_type(PER))) T VT;
     typedef __attribute__((ext_vector_type(PER))) float VF;
     constexpr int d = PER * 64;
@@ -129,13 +133,18 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
     const VF gm = *reinterpret_cast<const VF*>(gamma + lane * PER), bt = *reinterpret_cast<const VF*>(beta + lane * PER);
     float v[PER];
     float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) v[i] = to_f32(xv[i]);
+    if (drop_thresh) {
+        // the unfused path rounds the dropped value to T before the add: keep that rounding so both paths agree to the bit
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            v[i] = drop_keep(drop_seed, (uint64_t)(row * d + lane * PER + i), drop_thresh) ? to_f32(from_f32<T>(v[i] * drop_scale)) : 0.f;
+    }
     if (res) {
         const VT rv = *reinterpret_cast<const VT*>(res + row * d + lane * PER);
 #pragma unroll
-        for (int i = 0; i < PER; ++i) v[i] = to_f32(xv[i]) + to_f32(rv[i]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < PER; ++i) v[i] = to_f32(xv[i]);
+        for (int i = 0; i < PER; ++i) v[i] += to_f32(rv[i]);
     }
 #pragma unroll
     for (int i = 0; i < PER; ++i) s += v[i];
@@ -151,14 +160,16 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-// Backward: s = x + res, xhat = (s - mean) * rstd, gh = dy * gamma
-//   ds = rstd * (gh - mean_d(gh) - xhat * mean_d(gh * xhat))      (gradient of BOTH x and res)
+// Backward: s = dropout(x) + res, xhat = (s - mean) * rstd, gh = dy * gamma
+//   ds = rstd * (gh - mean_d(gh) - xhat * mean_d(gh * xhat))      (gradient of res; of x too when there is no dropout)
+//   dx = keep ? ds / (1-p) : 0                                     (second output, only with the fused dropout)
 //   dgamma[c] += sum_rows dy * xhat ; dbeta[c] += sum_rows dy     (register partials per wave -> LDS -> one atomic per column per block)
 template <typename T, int PER>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ res,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, T* __restrict__ ds, float* __restrict__ dgamma,
-                                                         float* __restrict__ dbeta, long M, int rows_per_block) {
+                                                         float* __restrict__ dbeta, long M, int rows_per_block, uint32_t drop_thresh, float drop_scale,
+                                                         uint64_t drop_seed, T* __restrict__ dx) {
     typedef __attribute__((ext_vector_type(PER))) T VT;
     typedef __attribute__((ext_vector_type(PER))) float VF;
     constexpr int d = PER * 64;
@@ -176,13 +187,20 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
         const VT xv = *reinterpret_cast<const VT*>(x + row * d + lane * PER);
         const VT gv = *reinterpret_cast<const VT*>(dy + row * d + lane * PER);
         float sv[PER];
+        bool keep[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { sv[i] = to_f32(xv[i]); keep[i] = true; }
+        if (drop_thresh) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                keep[i] = drop_keep(drop_seed, (uint64_t)(row * d + lane * PER + i), drop_thresh);
+                sv[i] = keep[i] ? to_f32(from_f32<T>(sv[i] * drop_scale)) : 0.f;
+            }
+        }
         if (res) {
             const VT rv = *reinterpret_cast<const VT*>(res + row * d + lane * PER);
 #pragma unroll
-            for (int i = 0; i < PER; ++i) sv[i] = to_f32(xv[i]) + to_f32(rv[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < PER; ++i) sv[i] = to_f32(xv[i]);
+            for (int i = 0; i < PER; ++i) sv[i] += to_f32(rv[i]);
         }
         float xh[PER], gh[PER], s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -199,6 +217,12 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
 #pragma unroll
         for (int i = 0; i < PER; ++i) o[i] = from_f32<T>(rs * (gh[i] - s1 - xh[i] * s2));
         *reinterpret_cast<VT*>(ds + row * d + lane * PER) = o;
+        if (drop_thresh) {
+            VT od;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) od[i] = keep[i] ? from_f32<T>(to_f32(o[i]) * drop_scale) : from_f32<T>(0.f);
+            *reinterpret_cast<VT*>(dx + row * d + lane * PER) = od;
+        }
     }
 #pragma unroll
     for (int i = 0; i < PER; ++i) { atomicAdd(&cg[lane * PER + i], ag[i]); atomicAdd(&cb[lane * PER + i], ab[i]); }
@@ -288,22 +312,30 @@ extern "C" int omr_instnorm_bwd(int dtype, const void* dxhat, const void* x, con
     }
 
 extern "C" int omr_add_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* out, float* mean,
-                                     float* rstd, long M, int d, float eps, void* stream) {
-    if (M <= 0 || d <= 0 || d % 64) return OMR_ERR_ARG;
+                                     float* rstd, long M, int d, float eps, float drop_p, unsigned long long drop_seed, void* stream) {
+    if (M <= 0 || d <= 0 || d % 64 || drop_p < 0.f || drop_p >= 1.f) return OMR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     int grid = cdiv(M, 4);
-    DISPATCH_T(dtype, { LN_DISPATCH_PER(add_ln_fwd_kernel, grid, 256, 0, s, (const T*)x, (const T*)res, gamma, beta, (T*)out, mean, rstd, M, eps) });
+    const uint32_t thresh = (uint32_t)((double)drop_p * 4294967296.0);
+    const float scale = 1.f / (1.f - drop_p);
+    DISPATCH_T(dtype, { LN_DISPATCH_PER(add_ln_fwd_kernel, grid, 256, 0, s, (const T*)x, (const T*)res, gamma, beta, (T*)out, mean, rstd, M, eps, thresh, scale,
+                                        (uint64_t)drop_seed) });
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }
 
 extern "C" int omr_add_layernorm_bwd(int dtype, const void* dy, const void* x, const void* res, const float* gamma, const float* mean,
-                                     const float* rstd, void* ds, float* dgamma, float* dbeta, long M, int d, void* stream) {
-    if (M <= 0 || d <= 0 || d % 64) return OMR_ERR_ARG;
+                                     const float* rstd, void* ds, float* dgamma, float* dbeta, long M, int d, float drop_p,
+                                     unsigned long long drop_seed, void* dx, void* stream) {
+    if (M <= 0 || d <= 0 || d % 64 || drop_p < 0.f || drop_p >= 1.f) return OMR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     int rpb = 32;
     int grid = cdiv(M, rpb);
-    DISPATCH_T(dtype, { LN_DISPATCH_PER(add_ln_bwd_kernel, grid, 256, 0, s, (const T*)dy, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)ds, dgamma, dbeta, M, rpb) });
+    const uint32_t thresh = (uint32_t)((double)drop_p * 4294967296.0);
+    const float scale = 1.f / (1.f - drop_p);
+    if (thresh && !dx) return OMR_ERR_ARG;
+    DISPATCH_T(dtype, { LN_DISPATCH_PER(add_ln_bwd_kernel, grid, 256, 0, s, (const T*)dy, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)ds, dgamma, dbeta, M, rpb,
+                                        thresh, scale, (uint64_t)drop_seed, (T*)dx) });
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }

@@ -121,14 +121,15 @@ class TransformerDecoderLayer(nn.Module):
 
     def forward(self, x, memory, window: int, self_key_bias, mem_key_bias):
         tr, p = self.training, self.dropout_p
-        sa = _dropout(self.self_attn.self_attention(x, True, window, self_key_bias, tr), p, tr)
-        x = Fn.AddLayerNormFn.apply(sa, x, self.norm1.weight, self.norm1.bias)
+        drop = (lambda: (p, next_seed())) if (tr and p > 0.0) else (lambda: None)      # dropout1/2/3 ride inside the add+LayerNorm kernels
+        sa = self.self_attn.self_attention(x, True, window, self_key_bias, tr)
+        x = Fn.AddLayerNormFn.apply(sa, x, self.norm1.weight, self.norm1.bias, drop())
         kv = self.multihead_attn.project_kv(memory)
-        ca = _dropout(self.multihead_attn.cross_attention(x, kv, mem_key_bias, tr), p, tr)
-        x = Fn.AddLayerNormFn.apply(ca, x, self.norm2.weight, self.norm2.bias)
+        ca = self.multihead_attn.cross_attention(x, kv, mem_key_bias, tr)
+        x = Fn.AddLayerNormFn.apply(ca, x, self.norm2.weight, self.norm2.bias, drop())
         h = _dropout(Fn.linear(x, self.linear1.weight, self.linear1.bias, relu=True, mask_own=True), p, tr)
-        ff = _dropout(Fn.linear(h, self.linear2.weight, self.linear2.bias), p, tr)
-        return Fn.AddLayerNormFn.apply(ff, x, self.norm3.weight, self.norm3.bias)
+        ff = Fn.linear(h, self.linear2.weight, self.linear2.bias)
+        return Fn.AddLayerNormFn.apply(ff, x, self.norm3.weight, self.norm3.bias, drop())
 
 
 class TransformerDecoder(nn.Module):

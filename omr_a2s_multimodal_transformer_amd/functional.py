@@ -240,20 +240,27 @@ class EmbedPEFn(Function):
 
 
 class AddLayerNormFn(Function):
-    """LayerNorm(x + res) (post-norm residual, torch nn/modules/transformer.py:1146-1154)."""
+    """LayerNorm(dropout(x) + res): the post-norm residual with its sublayer dropout in one kernel
+    (torch nn/modules/transformer.py:1146-1154).  drop = (p, seed) or None."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta):
-        out, mean, rstd = K.add_layernorm_fwd(x.contiguous(), res.contiguous(), gamma.omr_phys, beta.omr_phys)
-        ctx.gamma, ctx.beta = gamma, beta
+    def forward(ctx, x, res, gamma, beta, drop=None):
+        p, seed = drop if drop is not None else (0.0, 0)
+        out, mean, rstd = K.add_layernorm_fwd(x.contiguous(), res.contiguous(), gamma.omr_phys, beta.omr_phys, drop_p=p, drop_seed=seed)
+        ctx.gamma, ctx.beta, ctx.drop = gamma, beta, (p, seed)
         ctx.save_for_backward(x, res, mean, rstd)
         return out
 
     @staticmethod
     def backward(ctx, gy):
         x, res, mean, rstd = ctx.saved_tensors
-        ds = K.add_layernorm_bwd(gy.contiguous(), x.contiguous(), res.contiguous(), ctx.gamma.omr_phys, mean, rstd, ctx.gamma.omr_grad, ctx.beta.omr_grad)
-        return ds, ds, None, None
+        p, seed = ctx.drop
+        r = K.add_layernorm_bwd(gy.contiguous(), x.contiguous(), res.contiguous(), ctx.gamma.omr_phys, mean, rstd, ctx.gamma.omr_grad, ctx.beta.omr_grad,
+                                drop_p=p, drop_seed=seed)
+        if p > 0.0:
+            ds, dx = r
+            return dx, ds, None, None, None
+        return r, r, None, None, None
 
 
 class AttentionFn(Function):

@@ -190,7 +190,8 @@ def instnorm_bwd(dxhat: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, relu_mask
     return dx
 
 
-def add_layernorm_fwd(x: Tensor, res: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float = 1e-5):
+def add_layernorm_fwd(x: Tensor, res: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float = 1e-5, drop_p: float = 0.0, drop_seed: int = 0):
+    """LayerNorm(dropout(x) + res); drop_p = 0 is the plain residual add."""
     require_cuda(x, res, gamma, beta)
     d = x.shape[-1]
     M = x.numel() // d
@@ -200,19 +201,22 @@ def add_layernorm_fwd(x: Tensor, res: Optional[Tensor], gamma: Tensor, beta: Ten
     mean = torch.empty(M, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
     lib().call("omr_add_layernorm_fwd", dtype_code(x.dtype), ptr(x), ptr(res), ptr(gamma), ptr(beta), ptr(out), ptr(mean), ptr(rstd), M, d, eps,
-               cur_stream())
+               float(drop_p), int(drop_seed) & (2**64 - 1), cur_stream())
     return out, mean, rstd
 
 
-def add_layernorm_bwd(dy: Tensor, x: Tensor, res: Optional[Tensor], gamma: Tensor, mean: Tensor, rstd: Tensor, dgamma: Tensor, dbeta: Tensor) -> Tensor:
+def add_layernorm_bwd(dy: Tensor, x: Tensor, res: Optional[Tensor], gamma: Tensor, mean: Tensor, rstd: Tensor, dgamma: Tensor, dbeta: Tensor,
+                      drop_p: float = 0.0, drop_seed: int = 0):
+    """Returns ds (gradient of res, and of x without dropout); with drop_p > 0 returns (ds, dx)."""
     require_cuda(dy, x)
     d = x.shape[-1]
     M = x.numel() // d
     assert dy.is_contiguous() and dy.shape == x.shape and dgamma.dtype == torch.float32 and dbeta.dtype == torch.float32
     ds = torch.empty_like(x)
+    dx = torch.empty_like(x) if drop_p > 0.0 else None
     lib().call("omr_add_layernorm_bwd", dtype_code(x.dtype), ptr(dy), ptr(x), ptr(res), ptr(gamma), ptr(mean), ptr(rstd), ptr(ds), ptr(dgamma),
-               ptr(dbeta), M, d, cur_stream())
-    return ds
+               ptr(dbeta), M, d, float(drop_p), int(drop_seed) & (2**64 - 1), ptr(dx), cur_stream())
+    return ds if dx is None else (ds, dx)
 
 
 # ------------------------------------------------------------------------------------------------ convolutions

@@ -192,6 +192,28 @@ def test_add_layernorm(dtype, d):
     check(db, xs[3].grad, dtype, scale=8, what="ln dbeta")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_add_layernorm_fused_dropout_matches_dropout_then_add_ln(dtype):
+    """The sublayer dropout fused into the add+LayerNorm kernels uses omr_dropout's mask: both routes agree exactly."""
+    M, d, p, seed = 70, 256, 0.3, 1234
+    k = K()
+    x, res = q(rnd((M, d), 25), dtype).to(dev(), dtype), q(rnd((M, d), 26), dtype).to(dev(), dtype)
+    gamma, beta = (rnd((d,), 27) + 1.5).to(dev()), rnd((d,), 28).to(dev())
+    xd = k.dropout(x, p, seed)
+    ref, mean0, rstd0 = k.add_layernorm_fwd(xd, res, gamma, beta)
+    out, mean, rstd = k.add_layernorm_fwd(x, res, gamma, beta, drop_p=p, drop_seed=seed)
+    assert torch.equal(out, ref) and torch.equal(mean, mean0) and torch.equal(rstd, rstd0)
+    g = q(rnd((M, d), 29), dtype).to(dev(), dtype)
+    dg0, db0 = torch.zeros(d, device=dev()), torch.zeros(d, device=dev())
+    ds0 = k.add_layernorm_bwd(g, xd, res, gamma, mean0, rstd0, dg0, db0)
+    dg, db = torch.zeros(d, device=dev()), torch.zeros(d, device=dev())
+    ds, dx = k.add_layernorm_bwd(g, x, res, gamma, mean, rstd, dg, db, drop_p=p, drop_seed=seed)
+    assert torch.equal(ds, ds0)
+    assert torch.equal(dx, k.dropout(ds0, p, seed))
+    torch.testing.assert_close(dg, dg0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(db, db0, rtol=1e-5, atol=1e-5)
+
+
 # ------------------------------------------------------------------------------------------------ convolutions
 
 def nhwc(t):
