@@ -72,9 +72,12 @@ int omr_add_layernorm_bwd(int dtype, const void* dy, const void* x, const void* 
  * (encoder.py:65-70), Conv1d(k=1) head (decoder.py:98-102,146).  transA/transB: operand stored reduction-major.
  * split_k > 1 accumulates into fp32 C with atomics (C must hold the running sum / zeros).
  * colsum_a (nullable, transA only): colsum_a[m] += sum_k A[k][m] -- the bias gradient of a linear layer comes out of the
- * same pass that computes its weight gradient dW = dY^T . X. */
+ * same pass that computes its weight gradient dW = dY^T . X.
+ * drop_p > 0: nn.Dropout on the (activated) output, omr_dropout's mask over the flat [M][ldc] element index (FFN dropout,
+ * torch nn/modules/transformer.py:1197-1199). */
 int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C,
-             long ldc, const float* bias, int relu, int accumulate, int split_k, float* colsum_a, void* stream);
+             long ldc, const float* bias, int relu, int accumulate, int split_k, float* colsum_a, float drop_p,
+             unsigned long long drop_seed, void* stream);
 
 /* ---- convolutions (NHWC) --------------------------------------------------------------------------------- */
 /* nn.Conv2d 3x3 pad 1 (encoder.py:132-150) with fused bias + ReLU, optional fused InstanceNorm apply on the input

@@ -259,7 +259,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             const int c = lane + it * 64, row = c >> 3, kc = (c & 7) * 8;
             const int gr = m0 + wm * 64 + row, gc = n0 + wn * 64 + kc;
             if (gr >= g.M || gc >= g.N) continue;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * Cfg::CPITCH + kc);
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * Cfg::CPITCH + kc);
+            if (g.drop_thresh) {      // nn.Dropout after the activation: omr_dropout's mask over the flat [M][ldc] index
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    v[e] = drop_keep(g.drop_seed, (uint64_t)((long)gr * g.ldc + gc + e), g.drop_thresh) ? (bf16)((float)v[e] * g.drop_scale) : (bf16)0.f;
+            }
             TC* dst = C + (long)gr * g.ldc + gc;
             if (vec_ok && gc + 8 <= g.N && !g.accum) {
                 *reinterpret_cast<bf16x8*>(dst) = v;
@@ -284,6 +289,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                     if (row >= g.M) continue;
                     float v = acc[i][j][r] + bv;
                     if (g.relu) v = fmaxf(v, 0.f);
+                    if constexpr (!TA) {      // forward-type GEMMs only: the weight-gradient instantiations keep their lean atomic loop
+                        if (g.drop_thresh) v = drop_keep(g.drop_seed, (uint64_t)((long)row * g.ldc + col), g.drop_thresh) ? to_f32(from_f32<TC>(v)) * g.drop_scale : 0.f;
+                    }
                     TC* dst = C + (long)row * g.ldc + col;
                     if (g.atomic) {
                         if constexpr (sizeof(TC) == 4) atomicAdd((float*)dst, v);
@@ -316,7 +324,7 @@ template <typename T, typename TC> int launch(GemmArgs g, int ta, int tb, int sp
 
 extern "C" int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, int N, int K, const void* A, long lda,
                         const void* B, long ldb, void* C, long ldc, const float* bias, int relu, int accumulate,
-                        int split_k, float* colsum_a, void* stream) {
+                        int split_k, float* colsum_a, float drop_p, unsigned long long drop_seed, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return OMR_ERR_ARG;
     const int vec = dtype == OMR_BF16 ? 8 : 4;
     if (lda % vec || ldb % vec) return OMR_ERR_ARG;                       // 16-byte aligned rows
@@ -326,6 +334,8 @@ extern "C" int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, i
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.relu = relu; g.accum = accumulate; g.atomic = split_k > 1; g.colsum_a = colsum_a;
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (split_k > 1 || accumulate || transA))) return OMR_ERR_ARG;      // dropout needs the final value
+    g.drop_thresh = (unsigned)((double)drop_p * 4294967296.0); g.drop_scale = 1.f / (1.f - drop_p); g.drop_seed = drop_seed;
     if (colsum_a && !transA) return OMR_ERR_ARG;
     const int bk = dtype == OMR_BF16 ? 64 : 32;
     int len = cdiv(cdiv(K, split_k), bk) * bk;

@@ -127,7 +127,7 @@ class TransformerDecoderLayer(nn.Module):
         kv = self.multihead_attn.project_kv(memory)
         ca = self.multihead_attn.cross_attention(x, kv, mem_key_bias, tr)
         x = Fn.AddLayerNormFn.apply(ca, x, self.norm2.weight, self.norm2.bias, drop())
-        h = _dropout(Fn.linear(x, self.linear1.weight, self.linear1.bias, relu=True, mask_own=True), p, tr)
+        h = Fn.linear(x, self.linear1.weight, self.linear1.bias, relu=True, mask_own=True, drop=drop())     # FFN dropout in the GEMM epilogue
         ff = Fn.linear(h, self.linear2.weight, self.linear2.bias)
         return Fn.AddLayerNormFn.apply(ff, x, self.norm3.weight, self.norm3.bias, drop())
 

@@ -130,7 +130,7 @@ class LinearFn(Function):
     ``out_ld`` > N pads the output row stride (head: vocabulary rounded up to 8 for aligned rows)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, mask_own, out_ld, rows):
+    def forward(ctx, x, weight, bias, relu, mask_own, out_ld, rows, drop=None):
         w = wt(weight, x.dtype)
         w = w.view(w.shape[0], -1)           # [N_all, K]
         b = None if bias is None else bias.omr_phys
@@ -144,15 +144,17 @@ class LinearFn(Function):
             buf = torch.empty((M, out_ld), dtype=x.dtype, device=x.device)
             y2 = K.gemm(x2, w, bias=b, relu=relu, out=buf[:, :N])
         else:
-            y2 = K.gemm(x2, w, bias=b, relu=relu)
-        ctx.cfg = (relu, mask_own, tuple(x.shape), rows)
+            y2 = K.gemm(x2, w, bias=b, relu=relu, drop=drop)
+        if drop is not None:
+            assert relu and mask_own and not (out_ld and out_ld != N), "fused dropout: ReLU layers whose own backward applies (y > 0) / (1 - p)"
+        ctx.cfg = (relu, mask_own, tuple(x.shape), rows, 1.0 / (1.0 - drop[0]) if drop is not None else 1.0)
         ctx.weight, ctx.bias = weight, bias
         ctx.save_for_backward(x2, y2 if (relu and mask_own) else None)
         return y2.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, gy):
-        relu, mask_own, xshape, rows = ctx.cfg
+        relu, mask_own, xshape, rows, own_scale = ctx.cfg
         x2, y2 = ctx.saved_tensors
         weight, bias = ctx.weight, ctx.bias
         w = wt(weight, x2.dtype)
@@ -167,17 +169,17 @@ class LinearFn(Function):
         if g2.stride(1) != 1 or g2.stride(0) % 8:
             g2 = g2.contiguous()
         if relu and mask_own:
-            g2 = K.relu_bwd(g2.contiguous(), y2)
+            g2 = K.relu_bwd(g2.contiguous(), y2, own_scale)     # y2 is the stored (dropped) output: ReLU + dropout backward in one mask
         M = g2.shape[0]
         K.gemm(g2, x2, trans_a=True, trans_b=True, out=gw, accumulate=True, split_k=split_k_for(M, N, Kd), colsum_a=gb)   # dW and db in one pass
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.gemm(g2, w, trans_b=True).view(xshape)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
-def linear(x, weight, bias, relu=False, mask_own=True, out_ld=0, rows=None):
-    return LinearFn.apply(x, weight, bias, relu, mask_own, out_ld, rows)
+def linear(x, weight, bias, relu=False, mask_own=True, out_ld=0, rows=None, drop=None):
+    return LinearFn.apply(x, weight, bias, relu, mask_own, out_ld, rows, drop)
 
 
 class AddFn(Function):

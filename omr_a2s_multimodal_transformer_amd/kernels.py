@@ -23,7 +23,7 @@ def _rows2d(t: Tensor) -> Tuple[int, int, int]:
 
 def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = False, bias: Optional[Tensor] = None, relu: bool = False,
          out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None, accumulate: bool = False, split_k: int = 1,
-         colsum_a: Optional[Tensor] = None) -> Tensor:
+         colsum_a: Optional[Tensor] = None, drop: Optional[Tuple[float, int]] = None) -> Tensor:
     """C[M,N] (+)= act(opA(a) @ opB(b)^T + bias).  a is [M,K] ([K,M] if trans_a); b is [N,K] ([K,N] if trans_b)."""
     require_cuda(a, b, bias, out)
     assert a.dtype == b.dtype
@@ -42,7 +42,8 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = False, 
     if colsum_a is not None:
         assert trans_a and colsum_a.dtype == torch.float32 and colsum_a.numel() == M and colsum_a.is_contiguous()
     lib().call("omr_gemm", dtype_code(a.dtype), dtype_code(out.dtype), int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb,
-               ptr(out), ldc, ptr(bias), int(relu), int(accumulate), split_k, ptr(colsum_a), cur_stream())
+               ptr(out), ldc, ptr(bias), int(relu), int(accumulate), split_k, ptr(colsum_a), float(drop[0]) if drop else 0.0,
+               (int(drop[1]) & (2**64 - 1)) if drop else 0, cur_stream())
     return out
 
 

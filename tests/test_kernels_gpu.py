@@ -193,6 +193,19 @@ def test_add_layernorm(dtype, d):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_fused_dropout_matches_gemm_then_dropout(dtype):
+    """FFN dropout in the GEMM epilogue = omr_dropout applied to the activated output, to the bit."""
+    M, N, Kd, p, seed = 200, 320, 96, 0.25, 99
+    k = K()
+    a = q(rnd((M, Kd), 90, -1, 1), dtype).to(dev(), dtype)
+    w = q(rnd((N, Kd), 91, -1, 1), dtype).to(dev(), dtype)
+    bias = rnd((N,), 92, -1, 1).to(dev())
+    plain = k.gemm(a, w, bias=bias, relu=True)
+    fused = k.gemm(a, w, bias=bias, relu=True, drop=(p, seed))
+    assert torch.equal(fused, k.dropout(plain, p, seed))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_add_layernorm_fused_dropout_matches_dropout_then_add_ln(dtype):
     """The sublayer dropout fused into the add+LayerNorm kernels uses omr_dropout's mask: both routes agree exactly."""
     M, d, p, seed = 70, 256, 0.3, 1234
