@@ -437,6 +437,107 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x,
     }
 }
 
+// Row-walking form of the same op for the DSC blocks (16 x 256 maps, 128-256 channels: tensors of 30-70 MB where the
+// per-pixel kernel above is latency-bound at ~1.3 TB/s).  Thread = (image column, channel group): it walks RC rows of one
+// image with a 3x3 register window of the (normalised, zero-padded) input, so a pixel costs 3 new 16-byte loads
+// (two rows ahead are in flight behind this row's FMAs) instead of 9, and the InstanceNorm apply is paid once per loaded element
+// instead of once per tap.  Taps and bias sit in LDS as above.
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_walk_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd, const T* __restrict__ mask,
+                                                             float mask_scale, int B, int H, int Wd, int C, int flip, int RC) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N;
+    // taps [9][C] in the compute dtype (already mirrored when flip), read as ONE 16-byte fragment per tap per thread: lanes
+    // step 16 bytes, conflict-free, where scalar fp32 reads at a 32-byte lane stride were 8-way bank conflicted and
+    // dominated the kernel.  The fp32 bias follows (2 x 16 bytes per thread).
+    extern __shared__ __attribute__((aligned(16))) unsigned char wraw[];
+    T* wt = reinterpret_cast<T*>(wraw);
+    float* wbias = reinterpret_cast<float*>(wraw + (size_t)9 * C * sizeof(T));
+    for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) {
+        const int t = i / C, c = i % C;
+        wt[i] = w[c * 9 + (flip ? 8 - t : t)];
+    }
+    for (int i = threadIdx.x; i < C; i += blockDim.x) wbias[i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const int cv = C / VEC;
+    const int c = (threadIdx.x % cv) * VEC, j = blockIdx.x * (blockDim.x / cv) + threadIdx.x / cv;
+    if (j >= Wd) return;
+    const int chunks = cdiv(H, RC);
+    const int b = blockIdx.y / chunks, r0 = (blockIdx.y % chunks) * RC, r1 = min(H, r0 + RC);
+    float rs[VEC], nb[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        rs[e] = rstd ? rstd[b * C + c + e] : 1.f;
+        nb[e] = mean ? -mean[b * C + c + e] * rs[e] : 0.f;
+    }
+    const T* xb = x + (long)b * H * Wd * C + c;
+    const bool cl = j > 0, cr = j + 1 < Wd;
+    // raw row r of the three columns j-1, j, j+1 (zero fragments outside the image); `ok` tells convert() which are real
+    auto fetch = [&](int r, F (&raw)[3], bool& ok) {
+        ok = r >= 0 && r < H;
+        raw[0] = raw[1] = raw[2] = frag_zero<T>();
+        if (ok) {
+            const T* xr = xb + ((long)r * Wd + j) * C;
+            raw[1] = *reinterpret_cast<const F*>(xr);
+            if (cl) raw[0] = *reinterpret_cast<const F*>(xr - C);
+            if (cr) raw[2] = *reinterpret_cast<const F*>(xr + C);
+        }
+    };
+    const bool norm = mean != nullptr;
+    auto convert = [&](const F (&raw)[3], bool ok, F (&row)[3]) {   // normalise (rounded to T, as the MFMA convs do); padding stays exactly 0
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const bool v = ok && (kw == 1 || (kw == 0 ? cl : cr));
+            if (norm) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) row[kw][e] = v ? from_f32<T>(fmaf(to_f32(raw[kw][e]), rs[e], nb[e])) : from_f32<T>(0.f);
+            } else {
+                row[kw] = raw[kw];                                  // fetch() already zero-filled what lies outside
+            }
+        }
+    };
+    F win[3][3], rawa[3], rawb[3];
+    bool oka, okb;
+    fetch(r0 - 1, rawa, oka); convert(rawa, oka, win[0]);
+    fetch(r0, rawa, oka); convert(rawa, oka, win[1]);
+    fetch(r0 + 1, rawa, oka); convert(rawa, oka, win[2]);
+    fetch(r0 + 2, rawa, oka);                                    // two rows of loads stay in flight behind the math
+    for (int r = r0; r < r1; ++r) {
+        fetch(r + 3, rawb, okb);
+        asm volatile("" ::: "memory");                          // keep the taps in LDS (72+ registers otherwise)
+        float s[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(wbias + c + e);
+            s[e] = bv[0]; s[e + 1] = bv[1]; s[e + 2] = bv[2]; s[e + 3] = bv[3];
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const F wv = *reinterpret_cast<const F*>(wt + t * C + c);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s[e] = fmaf(to_f32(wv[e]), to_f32(win[t / 3][t % 3][e]), s[e]);
+        }
+        const long p = ((long)b * H + r) * Wd + j;
+        F o;
+        if (mask) {
+            const F mk = *reinterpret_cast<const F*>(mask + p * C + c);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(to_f32(mk[e]) > 0.f ? s[e] * mask_scale : 0.f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(s[e]);
+        }
+        *reinterpret_cast<F*>(y + p * C + c) = o;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) { win[0][kw] = win[1][kw]; win[1][kw] = win[2][kw]; }
+        convert(rawa, oka, win[2]);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) rawa[kw] = rawb[kw];
+        oka = okb;
+    }
+}
+
 // dW[c][tap] += sum_p dY[p][c] xin[p+tap][c];  db[c] += sum_p dY[p][c].
 // Thread = (image column j, channel group): it walks DOWN the rows of one image with a 3x3 register window of the
 // (normalised) input, so each pixel costs 3 new 16-byte x loads + 1 dY load for 9*VEC FMAs.  The 10*VEC partial sums stay
@@ -614,6 +715,16 @@ extern "C" int omr_dwconv3x3(int dtype, const void* x, const void* w, const floa
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return OMR_ERR_ARG;
     const int vec = dtype == OMR_BF16 ? 8 : 4;
     if (C % vec) return OMR_ERR_UNSUPPORTED;
+    const int cv = C / vec;
+    if (cv <= 256 && 256 % cv == 0 && H >= 4 && (size_t)10 * C * sizeof(float) <= 48 * 1024) {      // row walker (DSC blocks)
+        int RC = 8;                                              // rows per thread: 2 halo rows re-read per RC
+        while (RC < H && (long)cdiv(W, 256 / cv) * B * cdiv(H, RC) > 4096) RC *= 2;
+        dim3 gridw(cdiv(W, 256 / cv), B * cdiv(H, RC));
+        DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_walk_kernel<T>), gridw, 256, (size_t)9 * C * sizeof(T) + (size_t)C * sizeof(float), (hipStream_t)stream, (const T*)x, (const T*)w, bias,
+                                             (T*)y, in_mean, in_rstd, (const T*)out_mask, mask_scale, B, H, W, C, flip, RC));
+        OMR_CHECK_LAUNCH();
+        return OMR_OK;
+    }
     long total = (long)B * H * W * (C / vec);
     int grid = (int)((total + 1023) / 1024); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;   // >= 4 pixels x groups per thread amortise the weight staging
     DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T>), grid, 256, (size_t)10 * C * sizeof(float), (hipStream_t)stream, (const T*)x, (const T*)w, bias, (T*)y,
