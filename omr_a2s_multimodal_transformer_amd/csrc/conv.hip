@@ -540,27 +540,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_walk_kernel(const T* __restrict
 
 // dW[c][tap] += sum_p dY[p][c] xin[p+tap][c];  db[c] += sum_p dY[p][c].
 // Thread = (image column j, channel group): it walks DOWN the rows of one image with a 3x3 register window of the
-// (normalised) input, so each pixel costs 3 new 16-byte x loads + 1 dY load for 9*VEC FMAs.  The 10*VEC partial sums stay
-// in registers for the whole image column; wave shuffles fold the columns, then LDS and one global atomic per block.
-template <int R, typename T, typename LoadX>
-__device__ __forceinline__ void dw_wgrad_step(int r, int H, const T* __restrict__ dyp, long dy_row_stride, float (&xw)[3][3][Frag<T>::N],
-                                              float (&acc)[10][Frag<T>::N], LoadX loadx) {
-    typedef typename Frag<T>::type F;
-    constexpr int VEC = Frag<T>::N;
-    if (r >= H) return;
-    const F gv = *reinterpret_cast<const F*>(dyp + (long)r * dy_row_stride);
-    float g[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) { g[e] = to_f32(gv[e]); acc[9][e] += g[e]; }
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[kh * 3 + kw][e] += g[e] * xw[(R + kh) % 3][kw][e];
-    loadx(r + 2, xw[R % 3]);      // slot R held row r-1: refill it with row r+2
-}
-
+// normalised input (kept in the compute dtype) -- per pixel 3 new 16-byte x loads + 1 dY load, issued a row ahead of their
+// use, for 9*VEC FMAs.  The 10*VEC partial sums stay in registers for the whole column (splitting the rows over more
+// workgroups was tried: the 80-value fold below then dominates); wave shuffles fold the columns, then LDS and one global
+// atomic per weight per workgroup.
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd, int B, int H, int Wd, int C) {
@@ -577,35 +560,59 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
     if (j < Wd) {
-        float mu[VEC], rs[VEC];
+        const bool norm = mean != nullptr;
+        float rs[VEC], nb[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            mu[e] = mean ? mean[(long)b * C + cg * VEC + e] : 0.f;
             rs[e] = rstd ? rstd[(long)b * C + cg * VEC + e] : 1.f;
+            nb[e] = mean ? -mean[(long)b * C + cg * VEC + e] * rs[e] : 0.f;
         }
         const T* xb = x + (long)b * H * Wd * C + cg * VEC;
-        auto loadx = [&](int r, float (&row)[3][VEC]) {
+        const T* dyp = dy + ((long)b * H * Wd + j) * C + cg * VEC;
+        const long rstride = (long)Wd * C;
+        const bool cl = j > 0, cr = j + 1 < Wd;
+        auto fetch = [&](int r, F (&raw)[3], bool& ok) {
+            ok = r >= 0 && r < H;
+            raw[0] = raw[1] = raw[2] = frag_zero<T>();
+            if (ok) {
+                const T* xr = xb + ((long)r * Wd + j) * C;
+                raw[1] = *reinterpret_cast<const F*>(xr);
+                if (cl) raw[0] = *reinterpret_cast<const F*>(xr - C);
+                if (cr) raw[2] = *reinterpret_cast<const F*>(xr + C);
+            }
+        };
+        auto convert = [&](const F (&raw)[3], bool ok, F (&row)[3]) {   // zero padding lives in the normalised space
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int jj = j + kw - 1;
-                if (r >= 0 && r < H && jj >= 0 && jj < Wd) {
-                    const F v = *reinterpret_cast<const F*>(xb + ((long)r * Wd + jj) * C);
+                const bool v = ok && (kw == 1 || (kw == 0 ? cl : cr));
+                if (norm) {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) row[kw][e] = (to_f32(v[e]) - mu[e]) * rs[e];
+                    for (int e = 0; e < VEC; ++e) row[kw][e] = v ? from_f32<T>(fmaf(to_f32(raw[kw][e]), rs[e], nb[e])) : from_f32<T>(0.f);
                 } else {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) row[kw][e] = 0.f;   // zero padding lives in the normalised space
+                    row[kw] = raw[kw];
                 }
             }
         };
-        float xw[3][3][VEC];
-        loadx(-1, xw[0]); loadx(0, xw[1]); loadx(1, xw[2]);
-        const T* dyp = dy + ((long)b * H * Wd + j) * C + cg * VEC;
-        const long rs_ = (long)Wd * C;
-        for (int r = 0; r < H; r += 3) {
-            dw_wgrad_step<0, T>(r, H, dyp, rs_, xw, acc, loadx);
-            dw_wgrad_step<1, T>(r + 1, H, dyp, rs_, xw, acc, loadx);
-            dw_wgrad_step<2, T>(r + 2, H, dyp, rs_, xw, acc, loadx);
+        F win[3][3], raw[3], gcur, gnext = frag_zero<T>();
+        bool ok;
+        fetch(-1, raw, ok); convert(raw, ok, win[0]);
+        fetch(0, raw, ok); convert(raw, ok, win[1]);
+        fetch(1, raw, ok); convert(raw, ok, win[2]);
+        gcur = *reinterpret_cast<const F*>(dyp);
+        for (int r = 0; r < H; ++r) {
+            fetch(r + 2, raw, ok);                               // next row's operands fly behind this row's FMAs
+            if (r + 1 < H) gnext = *reinterpret_cast<const F*>(dyp + (long)(r + 1) * rstride);
+            float g[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { g[e] = to_f32(gcur[e]); acc[9][e] += g[e]; }
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[t][e] = fmaf(g[e], to_f32(win[t / 3][t % 3][e]), acc[t][e]);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) { win[0][kw] = win[1][kw]; win[1][kw] = win[2][kw]; }
+            convert(raw, ok, win[2]);
+            gcur = gnext;
         }
     }
     // fold the columns that share this lane's channel group (lanes cg, cg+ncg, ...), then LDS, then global
@@ -625,6 +632,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
         else if (db) atomicAdd(&db[c], red[i]);
     }
 }
+
 
 inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
