@@ -74,10 +74,14 @@ int omr_add_layernorm_bwd(int dtype, const void* dy, const void* x, const void* 
  * colsum_a (nullable, transA only): colsum_a[m] += sum_k A[k][m] -- the bias gradient of a linear layer comes out of the
  * same pass that computes its weight gradient dW = dY^T . X.
  * drop_p > 0: nn.Dropout on the (activated) output, omr_dropout's mask over the flat [M][ldc] element index (FFN dropout,
- * torch nn/modules/transformer.py:1197-1199). */
+ * torch nn/modules/transformer.py:1197-1199).
+ * row_group_operand != 0: the weight-side operand is a row-group view -- logical row i is physical row
+ * (i / row_group) * row_group_stride + row_group_base + i % row_group (row_group a multiple of 128); operand 1 = rows of B and
+ * bias entries, 2 = reduction rows of a transposed B, 3 = rows of C and colsum_a entries.  One call then covers the K|V rows
+ * of all decoder layers' packed in_proj_weight ([Wq;Wk;Wv], torch nn/modules/activation.py) laid back to back. */
 int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C,
              long ldc, const float* bias, int relu, int accumulate, int split_k, float* colsum_a, float drop_p,
-             unsigned long long drop_seed, void* stream);
+             unsigned long long drop_seed, int row_group, int row_group_stride, int row_group_base, int row_group_operand, void* stream);
 
 /* ---- convolutions (NHWC) --------------------------------------------------------------------------------- */
 /* nn.Conv2d 3x3 pad 1 (encoder.py:132-150) with fused bias + ReLU, optional fused InstanceNorm apply on the input

@@ -44,6 +44,11 @@ __device__ __forceinline__ TileId tile_of_block(const GemmArgs& g) {
 
 constexpr int BM = 128, BN = 128;
 
+// physical - logical row offset of the tile that starts at logical row i (tiles never straddle a group: host-checked)
+__device__ __forceinline__ long grp_delta(const GemmArgs& g, int operand, int i) {
+    return g.grp_operand == operand ? (long)(i / g.grp) * (g.grp_stride - g.grp) + g.grp_base : 0;
+}
+
 template <typename T> struct GemmCfg {
     static constexpr int VEC = Frag<T>::N;
     static constexpr int BK = 4 * KStep<T>::value;           // 64 (bf16) / 32 (fp32): 128 B per row
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const int kbeg = tile.split * g.ksplit_len;
     const int kend = min(g.K, kbeg + g.ksplit_len);
     const T* A = (const T*)g.A;
-    const T* B = (const T*)g.B;
+    const T* B = (const T*)g.B + grp_delta(g, 1, n0) * g.ldb;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int e = 0; e < Cfg::VEC; ++e) cs[e] = 0.f;
     const bool do_cs = TA && g.colsum_a != nullptr && tile.n == 0;
     sa.load(A, g.lda, m0, g.M, kbeg, kend, tid);
-    sb.load(B, g.ldb, n0, g.N, kbeg, kend, tid);
+    sb.load(B + grp_delta(g, 2, kbeg) * g.ldb, g.ldb, n0, g.N, kbeg, kend, tid);
     if (do_cs) sa.add_colsum(cs);
     sa.store(As, tid);
     sb.store(Bs, tid);
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         const bool more = (k0 + Cfg::BK) < kend;
         if (more) {
             sa.load(A, g.lda, m0, g.M, k0 + Cfg::BK, kend, tid);
-            sb.load(B, g.ldb, n0, g.N, k0 + Cfg::BK, kend, tid);
+            sb.load(B + grp_delta(g, 2, k0 + Cfg::BK) * g.ldb, g.ldb, n0, g.N, k0 + Cfg::BK, kend, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < Cfg::BK; ks += KStep<T>::value) {
@@ -218,11 +223,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int e = 0; e < Cfg::VEC; ++e) atomicAdd(&red[ml + e], cs[e]);
         __syncthreads();
-        if (tid < 128 && m0 + tid < g.M) atomicAdd(&g.colsum_a[m0 + tid], red[tid]);
+        if (tid < 128 && m0 + tid < g.M) atomicAdd(&g.colsum_a[m0 + tid + grp_delta(g, 3, m0)], red[tid]);
         __syncthreads();
     }
 
-    TC* C = (TC*)g.C;
+    TC* C = (TC*)g.C + grp_delta(g, 3, m0) * g.ldc;
+    const float* biasp = g.bias ? g.bias + grp_delta(g, 1, n0) : nullptr;
     if constexpr (SWAP) {
         // ---- bf16 C: lane = row (lane & 31) of M-block i; register r = column (r&3) + 8(r>>2) + 4(lane>>5) of N-block j
         typedef __attribute__((ext_vector_type(4))) bf16 B4;
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int col = n0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + hsel;
-                bv[r] = (g.bias != nullptr && tile.split == 0 && col < g.N) ? g.bias[col] : 0.f;
+                bv[r] = (biasp != nullptr && tile.split == 0 && col < g.N) ? biasp[col] : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + col_l;
             if (col >= g.N) continue;
-            const float bv = (g.bias != nullptr && tile.split == 0) ? g.bias[col] : 0.f;
+            const float bv = (biasp != nullptr && tile.split == 0) ? biasp[col] : 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -324,7 +330,8 @@ template <typename T, typename TC> int launch(GemmArgs g, int ta, int tb, int sp
 
 extern "C" int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, int N, int K, const void* A, long lda,
                         const void* B, long ldb, void* C, long ldc, const float* bias, int relu, int accumulate,
-                        int split_k, float* colsum_a, float drop_p, unsigned long long drop_seed, void* stream) {
+                        int split_k, float* colsum_a, float drop_p, unsigned long long drop_seed, int row_group, int row_group_stride,
+                        int row_group_base, int row_group_operand, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return OMR_ERR_ARG;
     const int vec = dtype == OMR_BF16 ? 8 : 4;
     if (lda % vec || ldb % vec) return OMR_ERR_ARG;                       // 16-byte aligned rows
@@ -335,6 +342,12 @@ extern "C" int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, i
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.relu = relu; g.accum = accumulate; g.atomic = split_k > 1; g.colsum_a = colsum_a;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (split_k > 1 || accumulate || transA))) return OMR_ERR_ARG;      // dropout needs the final value
+    g.grp = g.grp_stride = g.grp_base = g.grp_operand = 0;
+    if (row_group_operand) {
+        if (row_group_operand < 1 || row_group_operand > 3 || row_group <= 0 || row_group % 128 || row_group_stride < row_group || row_group_base < 0) return OMR_ERR_ARG;
+        if ((row_group_operand == 2 && !transB) || (row_group_operand == 1 && transB)) return OMR_ERR_ARG;
+        g.grp = row_group; g.grp_stride = row_group_stride; g.grp_base = row_group_base; g.grp_operand = row_group_operand;
+    }
     g.drop_thresh = (unsigned)((double)drop_p * 4294967296.0); g.drop_scale = 1.f / (1.f - drop_p); g.drop_seed = drop_seed;
     if (colsum_a && !transA) return OMR_ERR_ARG;
     const int bk = dtype == OMR_BF16 ? 64 : 32;

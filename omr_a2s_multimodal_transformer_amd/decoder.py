@@ -119,12 +119,14 @@ class TransformerDecoderLayer(nn.Module):
         self.norm1, self.norm2, self.norm3 = LayerNorm(d_model), LayerNorm(d_model), LayerNorm(d_model)
         self.dropout_p = dropout
 
-    def forward(self, x, memory, window: int, self_key_bias, mem_key_bias):
+    def forward(self, x, memory, window: int, self_key_bias, mem_key_bias, kv=None):
+        """kv: this layer's cross-attention K|V of `memory` when the decoder projected all layers at once."""
         tr, p = self.training, self.dropout_p
         drop = (lambda: (p, next_seed())) if (tr and p > 0.0) else (lambda: None)      # dropout1/2/3 ride inside the add+LayerNorm kernels
         sa = self.self_attn.self_attention(x, True, window, self_key_bias, tr)
         x = Fn.AddLayerNormFn.apply(sa, x, self.norm1.weight, self.norm1.bias, drop())
-        kv = self.multihead_attn.project_kv(memory)
+        if kv is None:
+            kv = self.multihead_attn.project_kv(memory)
         ca = self.multihead_attn.cross_attention(x, kv, mem_key_bias, tr)
         x = Fn.AddLayerNormFn.apply(ca, x, self.norm2.weight, self.norm2.bias, drop())
         h = Fn.linear(x, self.linear1.weight, self.linear1.bias, relu=True, mask_own=True, drop=drop())     # FFN dropout in the GEMM epilogue
@@ -211,6 +213,34 @@ class Decoder(nn.Module):
             return torch.zeros(mask.shape, dtype=torch.float32, device=mask.device).masked_fill(mask, float("-inf"))
         return mask.contiguous()
 
+    def _cross_kv_pack(self, dt):
+        """Row-group views over the packed cross-attention in_proj parameters of all layers, valid when the flat buffer holds
+        them back to back (params._placement_order; checked here on every call, so any other layout just takes the per-layer path)."""
+        layers = self.transformer_decoder.layers
+        ws = [l.multihead_attn.in_proj_weight for l in layers]
+        bs = [l.multihead_attn.in_proj_bias for l in layers]
+        if len(layers) < 2 or getattr(ws[0], "omr_phys", None) is None:
+            return None
+        d = ws[0].shape[1]
+        if (2 * d) % 128:
+            return None
+        L = len(layers)
+
+        def block(tensors, rows):
+            t0 = tensors[0]
+            step = t0.numel() * t0.element_size()
+            if any(t.data_ptr() != t0.data_ptr() + i * step or not t.is_contiguous() for i, t in enumerate(tensors)):
+                return None
+            return torch.as_strided(t0, (L * rows,) + tuple(t0.shape[1:]), t0.stride())
+
+        w = block([Fn.wt(p, dt) for p in ws], 3 * d)
+        gw = block([p.omr_grad for p in ws], 3 * d)
+        b = block([p.omr_phys for p in bs], 3 * d)
+        gb = block([p.omr_grad for p in bs], 3 * d)
+        if w is None or gw is None or b is None or gb is None:
+            return None
+        return dict(L=L, d=d, w=w, gw=gw, b=b, gb=gb)
+
     # ---- KV-cached greedy decoding (SURVEY.md section 8f rank 1).  The reference re-runs the whole prefix every step
     #      (model.py:184-193, O(T^3)); here each step projects ONE token, appends its self-attention K|V to a cache and
     #      reads the cross-attention K|V that were projected once.  Same kernels, same per-row arithmetic order.
@@ -266,8 +296,16 @@ class Decoder(nn.Module):
         # tgt_key_padding_mask = (tgt == 0).float() is ADDED (+1.0); dropped when there is no memory mask (decoder.py:131-132)
         self_bias = None if mem_mask is None else (tgt == 0).to(torch.float32).contiguous()
         window = self.attn_window if self.attn_window > 0 else -1
-        for layer in self.transformer_decoder.layers:
-            x = layer(x, memory, window, self_bias, mem_bias)
+        layers = self.transformer_decoder.layers
+        pack = self._cross_kv_pack(dt)
+        kvs = [None] * len(layers)
+        if pack is not None:
+            sink = Fn.KVGradSink()
+            kvs = Fn.FusedCrossKVFn.apply(memory, pack, sink)
+            for li, kv in enumerate(kvs):
+                kv.omr_grad_sink = (sink, li)
+        for layer, kv in zip(layers, kvs):
+            x = layer(x, memory, window, self_bias, mem_bias, kv)
         V = self.output_size
         logits = Fn.linear(x, self.out_layer.weight, self.out_layer.bias, out_ld=K.round_up(V, 8))  # [B,T,V], row pitch round_up(V,8)
         return logits.permute(0, 2, 1)  # [B, V, T] (decoder.py:145-146)

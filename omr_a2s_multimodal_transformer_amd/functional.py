@@ -281,6 +281,7 @@ class AttentionFn(Function):
         o, lse = K.attn_fwd(q, k, v, nhead, causal=causal, window=window, key_bias=key_bias, blk_lq=blk_lq, blk_lkv=blk_lkv,
                             dropout_p=dropout_p, seed=seed)
         ctx.cfg = (nhead, causal, window, dropout_p, seed, kv is None, d)
+        ctx.kv_sink = getattr(kv, "omr_grad_sink", None) if kv is not None else None     # (KVGradSink, layer): see FusedCrossKVFn
         ctx.save_for_backward(q_or_qkv, kv, o, lse, key_bias, blk_lq, blk_lkv)
         return o
 
@@ -296,12 +297,76 @@ class AttentionFn(Function):
             dkv = None
         else:
             dqkv = torch.empty_like(q_or_qkv)
-            dkv = torch.empty_like(kv)
+            dkv = torch.empty_like(kv) if ctx.kv_sink is None else ctx.kv_sink[0].slot(kv, ctx.kv_sink[1])
             q, k, v = q_or_qkv, kv[..., :d], kv[..., d:]
             dq, dk, dv = dqkv, dkv[..., :d], dkv[..., d:]
         K.attn_bwd(q, k, v, o, go, lse, dq, dk, dv, nhead, causal=causal, window=window, key_bias=key_bias, blk_lq=blk_lq, blk_lkv=blk_lkv,
                    dropout_p=dropout_p, seed=seed)
         return dqkv, dkv, None, None, None, None, None, None, None, None
+
+
+class KVGradSink:
+    """Shared landing buffer for the K|V gradients of all decoder layers: each layer's attention backward writes its
+    [B,S,2d] gradient straight into its column block of one [B,S,L*2d] tensor, so FusedCrossKVFn.backward can run ONE
+    weight-gradient GEMM and ONE data-gradient GEMM over it -- no per-layer gradient tensors, no gradient adds."""
+
+    def __init__(self):
+        self.buf = None
+
+    def slot(self, kv: Tensor, layer: int) -> Tensor:
+        width = kv.shape[-1]
+        if self.buf is None:
+            self.buf = torch.empty((kv.shape[0], kv.shape[1], kv.stride(1)), dtype=kv.dtype, device=kv.device)
+        return self.buf[..., layer * width:(layer + 1) * width]
+
+    def take(self):
+        buf, self.buf = self.buf, None
+        return buf
+
+
+class FusedCrossKVFn(Function):
+    """K|V projections of the encoder memory for ALL decoder layers in one GEMM (nn.MultiheadAttention in_proj rows
+    [d, 3d) of every layer, torch nn/functional.py multi_head_attention_forward / decoder.py:86-95): the memory is the same
+    tensor in every layer, so it is read once instead of L times, and its gradient is one GEMM over the concatenated K|V
+    gradients instead of L GEMMs plus L-1 gradient adds.  `pack` holds row-group views of the layers' packed in_proj
+    parameters where they lie back to back in the flat buffer (params._placement_order).  Returns L views [B,S,2d] of one
+    [B,S,L*2d] buffer."""
+
+    @staticmethod
+    def forward(ctx, memory, pack, sink):
+        L, d = pack["L"], pack["d"]
+        mem2 = memory.reshape(-1, d)
+        Rm = mem2.shape[0]
+        out = torch.empty((Rm, L * 2 * d), dtype=memory.dtype, device=memory.device)
+        K.gemm_row_groups(mem2, pack["w"], out, Rm, L * 2 * d, d, bias=pack["b"], group=(2 * d, 3 * d, d, 1))
+        ctx.pack, ctx.sink, ctx.mshape = pack, sink, tuple(memory.shape)
+        ctx.save_for_backward(mem2)
+        kv_all = out.view(memory.shape[0], memory.shape[1], L * 2 * d)
+        return tuple(kv_all[..., l * 2 * d:(l + 1) * 2 * d] for l in range(L))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        pack, (mem2,) = ctx.pack, ctx.saved_tensors
+        L, d = pack["L"], pack["d"]
+        Rm = mem2.shape[0]
+        buf = ctx.sink.take()
+        if buf is None:
+            buf = torch.empty((ctx.mshape[0], ctx.mshape[1], L * 2 * d), dtype=mem2.dtype, device=mem2.device)
+        for l, g in enumerate(grads):           # anything that did not land in the sink (or a missing gradient) is copied in
+            dst = buf[..., l * 2 * d:(l + 1) * 2 * d]
+            if g is None:
+                dst.zero_()
+            elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
+                dst.copy_(g)
+        g2 = buf.view(Rm, L * 2 * d)
+        K.gemm_row_groups(g2, mem2, pack["gw"], L * 2 * d, d, Rm, trans_a=True, trans_b=True, accumulate=True, split_k=split_k_for(Rm, L * 2 * d, d),
+                          colsum_a=pack["gb"], group=(2 * d, 3 * d, d, 3))
+        dmem = None
+        if ctx.needs_input_grad[0]:
+            dmem = torch.empty((Rm, d), dtype=mem2.dtype, device=mem2.device)
+            K.gemm_row_groups(g2, pack["w"], dmem, Rm, d, L * 2 * d, trans_b=True, group=(2 * d, 3 * d, d, 2))
+            dmem = dmem.view(ctx.mshape)
+        return dmem, None, None
 
 
 class CrossEntropyFn(Function):

@@ -43,7 +43,28 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = False, 
         assert trans_a and colsum_a.dtype == torch.float32 and colsum_a.numel() == M and colsum_a.is_contiguous()
     lib().call("omr_gemm", dtype_code(a.dtype), dtype_code(out.dtype), int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb,
                ptr(out), ldc, ptr(bias), int(relu), int(accumulate), split_k, ptr(colsum_a), float(drop[0]) if drop else 0.0,
-               (int(drop[1]) & (2**64 - 1)) if drop else 0, cur_stream())
+               (int(drop[1]) & (2**64 - 1)) if drop else 0, 0, 0, 0, 0, cur_stream())
+    return out
+
+
+def gemm_row_groups(a: Tensor, b: Tensor, out: Tensor, M: int, N: int, Kd: int, *, trans_a: bool = False, trans_b: bool = False,
+                    bias: Optional[Tensor] = None, accumulate: bool = False, split_k: int = 1, colsum_a: Optional[Tensor] = None,
+                    group: Tuple[int, int, int, int] = (0, 0, 0, 0)) -> Tensor:
+    """omr_gemm over a row-group view of the weight-side operand (include/omr_hip.h): `group` = (rows per group, physical
+    group stride, first row inside a group, operand 1|2|3).  The grouped tensor (b, or out/colsum_a/bias) is the PHYSICAL
+    2-D block that contains every group; M, N, Kd are the logical GEMM sizes, so only strides are taken from the tensors."""
+    require_cuda(a, b, bias, out, colsum_a)
+    assert a.dtype == b.dtype and a.dim() == b.dim() == out.dim() == 2 and a.stride(1) == b.stride(1) == out.stride(1) == 1
+    grp, stride, base, operand = group
+    ngroups = {1: N, 2: Kd, 3: M}[operand] // grp
+    phys_rows = (ngroups - 1) * stride + base + grp
+    grouped = out if operand == 3 else b
+    assert grouped.shape[0] >= phys_rows, f"grouped operand has {grouped.shape[0]} rows, the view needs {phys_rows}"
+    for vec, need in ((bias, operand == 1), (colsum_a, operand == 3)):
+        if vec is not None:
+            assert vec.dtype == torch.float32 and vec.is_contiguous() and vec.numel() >= (phys_rows if need else 0)
+    lib().call("omr_gemm", dtype_code(a.dtype), dtype_code(out.dtype), int(trans_a), int(trans_b), M, N, Kd, ptr(a), a.stride(0), ptr(b), b.stride(0),
+               ptr(out), out.stride(0), ptr(bias), 0, int(accumulate), split_k, ptr(colsum_a), 0.0, 0, grp, stride, base, operand, cur_stream())
     return out
 
 

@@ -34,6 +34,31 @@ def _inverse(perm: Tuple[int, ...]) -> Tuple[int, ...]:
     return tuple(inv)
 
 
+# Parameters that are placed back to back (in layer order) so that one GEMM can run over all of them through a row-group
+# view (omr_gemm row_group_*): the packed cross-attention in_proj matrices / biases of all decoder layers, whose K|V rows
+# project the SAME encoder memory in every layer (functional.FusedCrossKVFn).  Placement is a memory-layout choice only:
+# names, shapes and state-dict order are untouched.
+_GROUPED_SUFFIXES = ("multihead_attn.in_proj_weight", "multihead_attn.in_proj_bias")
+
+
+def _placement_order(named_params: List[Tuple[str, nn.Parameter]]) -> List[Tuple[str, nn.Parameter]]:
+    order: List[Tuple[str, nn.Parameter]] = []
+    done = set()
+    for n, p in named_params:
+        if n in done:
+            continue
+        suffix = next((s for s in _GROUPED_SUFFIXES if n.endswith(s)), None)
+        if suffix is None:
+            order.append((n, p))
+            done.add(n)
+            continue
+        for n2, p2 in named_params:             # pull every member of the family here, in model (layer) order
+            if n2.endswith(suffix) and n2 not in done and p2.shape == p.shape:
+                order.append((n2, p2))
+                done.add(n2)
+    return order
+
+
 class FlatParams:
     def __init__(self, named_params: List[Tuple[str, nn.Parameter]], device: torch.device, compute_dtype: torch.dtype):
         self.names = [n for n, _ in named_params]
@@ -42,7 +67,7 @@ class FlatParams:
         self.compute_dtype = compute_dtype
         self.offsets: Dict[str, Tuple[int, int]] = {}
         off = 0
-        for n, p in named_params:
+        for n, p in _placement_order(named_params):
             self.offsets[n] = (off, p.numel())
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
