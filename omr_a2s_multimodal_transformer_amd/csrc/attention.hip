@@ -142,22 +142,27 @@ __device__ __forceinline__ bool attn_keep_hi(uint32_t x, uint32_t thr32) { retur
 
 // ------------------------------------------------------------------------------------------------
 // Forward.  grid = (ceil(T/128), H, B); wave w owns query rows q0 + 32w .. +31; KV tiles of 64 keys.
-template <typename T, int HD>
+// SPLITW (T <= 32: KV-cached greedy decode, one query row): the four waves would own the same 32 rows, so they split the KEYS
+// instead -- 256 keys are staged per step, wave w takes keys [64w, 64w+64) of them -- and their (max, sum, O) partials are
+// merged through LDS at the end.  Same arithmetic per score, a quarter of the serial tile walk.
+template <typename T, int HD, bool SPLITW>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     typedef typename Frag<T>::type F;
     constexpr int VEC = ACfg<T>::VEC, NFR = ACfg<T>::NFR, KS = KStep<T>::value;
     constexpr int NKS = HD / KS, NDB = HD / 32, BKV = 64;
+    constexpr int NTL = SPLITW ? 4 : 1, BST = BKV * NTL;        // keys staged per step
     constexpr int PK = HD + VEC;          // Ks pitch
-    constexpr int PV = BKV + 4;   // Vt pitch: 136 B (bf16) / 272 B (fp32) -> conflict-free permuted reads
-    __shared__ __attribute__((aligned(16))) T Ks[BKV * PK];
+    constexpr int PV = BST + 4;   // Vt pitch: 136 B (bf16) / 272 B (fp32) -> conflict-free permuted reads
+    __shared__ __attribute__((aligned(16))) T Ks[BST * PK];
     constexpr bool TRD = std::is_same<T, bf16>::value;          // bf16: V is staged row-major and read with tr reads
     __shared__ __attribute__((aligned(16))) T Vt[TRD ? 8 : HD * PV];
-    __shared__ __attribute__((aligned(16))) T Vs[TRD ? BKV * PK : 8];
-    __shared__ __attribute__((aligned(16))) float bias_s[BKV];
+    __shared__ __attribute__((aligned(16))) T Vs[TRD ? BST * PK : 8];
+    __shared__ __attribute__((aligned(16))) float bias_s[BST];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
-    const int q = q0 + wave * 32 + (lane & 31);
+    const int q = q0 + (SPLITW ? 0 : wave * 32) + (lane & 31);
+    const int kboff = SPLITW ? wave * BKV : 0;                  // this wave's keys inside the staged block
     const T* Q = (const T*)a.q + (long)b * a.bsq + h * HD;
     const T* K = (const T*)a.k + (long)b * a.bsk + h * HD;
     const T* V = (const T*)a.v + (long)b * a.bsv + h * HD;
@@ -184,22 +189,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         kv_end = min(a.S, q0 + 128);
         if (a.window > 0 && a.window < a.T) kv_beg = max(0, q0 - a.window) / BKV * BKV;
     }
-    RowTile<T, HD, BKV> kt, vt;
+    RowTile<T, HD, BST> kt, vt;
     float bias_r = 0.f;
-    auto prefetch = [&](int kv0) {
-        kt.load(K, a.ldk, kv0, a.S, tid);
-        vt.load(V, a.ldv, kv0, a.S, tid);
-        if (tid < BKV) bias_r = (a.key_bias && kv0 + tid < a.S) ? a.key_bias[(long)b * a.S + kv0 + tid] * LOG2E : 0.f;
+    auto prefetch = [&](int kvb) {
+        kt.load(K, a.ldk, kvb, a.S, tid);
+        vt.load(V, a.ldv, kvb, a.S, tid);
+        if (tid < BST) bias_r = (a.key_bias && kvb + tid < a.S) ? a.key_bias[(long)b * a.S + kvb + tid] * LOG2E : 0.f;
     };
     if (kv_beg < kv_end) prefetch(kv_beg);
-    for (int kv0 = kv_beg; kv0 < kv_end; kv0 += BKV) {
+    for (int kvb = kv_beg; kvb < kv_end; kvb += BST) {
         __syncthreads();
         kt.template store<PK>(Ks, tid);
         if constexpr (TRD) vt.template store<PK>(Vs, tid);
         else vt.template store_t<PV>(Vt, tid);
-        if (tid < BKV) bias_s[tid] = bias_r;
+        if (tid < BST) bias_s[tid] = bias_r;
         __syncthreads();
-        if (kv0 + BKV < kv_end) prefetch(kv0 + BKV);
+        if (kvb + BST < kv_end) prefetch(kvb + BST);
+        const int kv0 = kvb + kboff;                            // first key of this wave's 64-key tile
 
         f32x16 st[2];
 #pragma unroll
@@ -208,13 +214,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) st[mb][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                const F kf = *reinterpret_cast<const F*>(&Ks[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
+                const F kf = *reinterpret_cast<const F*>(&Ks[(kboff + mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
                 mma32(st[mb], kf, qf[ks]);
             }
         }
         // scores -> log2-domain logits (scale and bias pre-multiplied by log2 e), running max.  Tiles that are entirely
         // visible for this wave's 32 query rows (the common case) skip every per-element mask test.
-        const int qw0 = q0 + wave * 32;
+        const int qw0 = q0 + (SPLITW ? 0 : wave * 32);
         const bool full = (kv0 + BKV <= a.S) && (qw0 + 32 <= a.T) && lq < 0 &&
                           (!a.causal || (kv0 + BKV - 1 <= qw0 && (!win_on || kv0 >= qw0 + 31 - a.window)));
         float mx = -INFINITY;
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 bz = *reinterpret_cast<const f32x4*>(&bias_s[mb * 32 + 8 * g + 4 * hh]);
+                    const f32x4 bz = *reinterpret_cast<const f32x4*>(&bias_s[kboff + mb * 32 + 8 * g + 4 * hh]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float sv = fmaf(st[mb][4 * g + e], sc2, bz[e]);
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 bz = *reinterpret_cast<const f32x4*>(&bias_s[mb * 32 + 8 * g + 4 * hh]);
+                    const f32x4 bz = *reinterpret_cast<const f32x4*>(&bias_s[kboff + mb * 32 + 8 * g + 4 * hh]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float sv = fmaf(st[mb][4 * g + e], sc2, bz[e]);
@@ -286,12 +292,49 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 const F pf = acc_to_frag<T>(st[mb], s);
 #pragma unroll
                 for (int d = 0; d < NDB; ++d) {
-                    const F vf = kperm_frag<T>(Vs, PK, Vt, PV, mb * 32, s, d * 32, lane);
+                    const F vf = kperm_frag<T>(Vs, PK, Vt, PV, kboff + mb * 32, s, d * 32, lane);
                     mma32(acc_o[d], vf, pf);
                 }
             }
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if constexpr (SPLITW) {
+        // merge the four waves' partial softmaxes of the same 32 query rows (log2 domain): the staging tiles are dead
+        __syncthreads();
+        float* o_s = reinterpret_cast<float*>(Ks);              // [4][HD][32]
+        float* m_s = o_s + 4 * HD * 32;                         // [4][32]
+        float* l_s = m_s + 4 * 32;
+        static_assert((4 * HD * 32 + 8 * 32) * sizeof(float) <= sizeof(T) * BST * PK, "merge scratch fits in the K tile");
+        const int qi = lane & 31;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_s[(wave * HD + d * 32 + acc_row(r, lane)) * 32 + qi] = acc_o[d][r];
+        if (hh == 0) { m_s[wave * 32 + qi] = m_run; l_s[wave * 32 + qi] = l_tot; }
+        __syncthreads();
+        if (wave != 0) return;
+        float mm = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mm = fmaxf(mm, m_s[w * 32 + qi]);
+        float wsc[4];
+        l_tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = m_s[w * 32 + qi];
+            wsc[w] = mw == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw - mm);
+            l_tot += l_s[w * 32 + qi] * wsc[w];
+        }
+        m_run = mm;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += o_s[(w * HD + d * 32 + acc_row(r, lane)) * 32 + qi] * wsc[w];
+                acc_o[d][r] = v;
+            }
+    }
     const float inv = l_tot > 0.f ? a.drop_scale / l_tot : 0.f;      // dropout rescale folded in (1 when p = 0)
     if (q < a.T) {
         T* O = (T*)a.o + (long)b * a.bso + (long)q * a.ldo + h * HD;
@@ -605,8 +648,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 }
 
 template <typename T, int HD> int run_fwd(const AttnArgs& a, hipStream_t s) {
+    if (a.T <= 32 && a.S > 64) {        // a single 32-row query block: split the keys over the waves instead
+        hipLaunchKernelGGL((attn_fwd_kernel<T, HD, true>), dim3(1, a.H, a.B), dim3(256), 0, s, a);
+        OMR_CHECK_LAUNCH();
+        return OMR_OK;
+    }
     dim3 grid(cdiv(a.T, 128), a.H, a.B);
-    hipLaunchKernelGGL((attn_fwd_kernel<T, HD>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, HD, false>), grid, dim3(256), 0, s, a);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }

@@ -345,6 +345,9 @@ ATTN_CASES = [  # name, T, S, d, nhead, causal, window, key_bias kind, blk
     ("cross_bool", 40, 200, 256, 4, False, -1, "neginf", False),
     ("cross_plus1", 129, 77, 128, 4, False, -1, "plus1", False),
     ("cross_blk_quirk", 50, 90, 256, 4, False, -1, None, True),
+    ("decode_one_query", 1, 700, 256, 4, False, -1, "plus1", False),      # T <= 32: the forward splits the keys over the waves
+    ("decode_few_queries", 20, 333, 128, 4, False, -1, "neginf", False),
+    ("decode_blk_quirk", 8, 130, 256, 4, False, -1, None, True),
 ]
 
 
