@@ -291,3 +291,36 @@ def test_kv_cached_decode_matches_full_rerun_bf16_long():
     a, _ = m._greedy(mem, use_cache=True)
     b, _ = m._greedy(mem, use_cache=False)
     assert a == b and len(a) >= 1
+
+
+def test_decoder_bucket_is_final_when_backward_crosses_the_memory_boundary():
+    """DDP overlap contract (ddp.py): the decoder bucket's all-reduce is enqueued when backward reaches the encoder->decoder
+    memory hand-off.  Every decoder-side gradient -- including the embedding's and the fused cross-attention K|V
+    projection's, whose nodes are not ancestors of the memory gradient -- must already be final at that moment."""
+    from omr_a2s_multimodal_transformer_amd.ddp import GradReducer
+
+    class Probe(GradReducer):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.snap = {}
+
+        def reduce_bucket(self, i):
+            if i not in self.snap:
+                b, e = self.buckets[i]
+                self.snap[i] = self.flat.grad[b:e].clone()
+
+    V = 50
+    m, w2i = make_transformer(V, ModelConfig(num_layers=3, **NO_DROP), 41)
+    m.train()
+    m.teacher_forcing_prob = 0.0
+    real = m.attach_reducer()
+    probe = Probe(m._flat, None, real.buckets)
+    m._reducer = probe
+    x, xl, y_in, y_out = (t.to(DEV) for t in syn.synthetic_unimodal_batch(2, 32, 64, 10, V, w2i["<sos>"], w2i["<eos>"], seed=5))
+    m.zero_grad()
+    m.compute_loss(m(x, xl, y_in), y_out).backward()
+    assert 1 in probe.snap and 0 not in probe.snap          # only the decoder bucket fired during backward
+    b, e = probe.buckets[1]
+    final = m._flat.grad[b:e]
+    assert final.abs().max() > 0
+    assert torch.equal(probe.snap[1], final), "a decoder gradient changed after the bucket was handed to the all-reduce"
