@@ -182,10 +182,23 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
     float ag[PER], ab[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) ag[i] = ab[i] = 0.f;
-    for (long row = r0 + wv; row < r0 + rows_per_block && row < M; row += nw) {
-        const float mu = mean[row], rs = rstd[row];
-        const VT xv = *reinterpret_cast<const VT*>(x + row * d + lane * PER);
-        const VT gv = *reinterpret_cast<const VT*>(dy + row * d + lane * PER);
+    // the next row's operands are requested before this row's math (a wave walks its rows one after another)
+    const long rend = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+    VT xn, gn, rn;
+    float mun = 0.f, rsn = 1.f;
+    auto fetch = [&](long row) {
+        if (row < rend) {
+            mun = mean[row]; rsn = rstd[row];
+            xn = *reinterpret_cast<const VT*>(x + row * d + lane * PER);
+            gn = *reinterpret_cast<const VT*>(dy + row * d + lane * PER);
+            if (res) rn = *reinterpret_cast<const VT*>(res + row * d + lane * PER);
+        }
+    };
+    fetch(r0 + wv);
+    for (long row = r0 + wv; row < rend; row += nw) {
+        const float mu = mun, rs = rsn;
+        const VT xv = xn, gv = gn, rv = rn;
+        fetch(row + nw);
         float sv[PER];
         bool keep[PER];
 #pragma unroll
@@ -198,7 +211,6 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
             }
         }
         if (res) {
-            const VT rv = *reinterpret_cast<const VT*>(res + row * d + lane * PER);
 #pragma unroll
             for (int i = 0; i < PER; ++i) sv[i] += to_f32(rv[i]);
         }
@@ -337,7 +349,7 @@ extern "C" int omr_add_layernorm_bwd(int dtype, const void* dy, const void* x, c
                                      unsigned long long drop_seed, void* dx, void* stream) {
     if (M <= 0 || d <= 0 || d % 64 || drop_p < 0.f || drop_p >= 1.f) return OMR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    int rpb = 32;
+    int rpb = 64;                        // fewer, longer workgroups: each ends with 2 d atomics onto the same 16 cache lines
     int grid = cdiv(M, rpb);
     const uint32_t thresh = (uint32_t)((double)drop_p * 4294967296.0);
     const float scale = 1.f / (1.f - drop_p);
