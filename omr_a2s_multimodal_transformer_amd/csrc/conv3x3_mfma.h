@@ -204,9 +204,21 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
             if (!single) stage_weights(c0);
             __syncthreads();
             // ---- nine shifted GEMMs out of LDS
+            // Zero-dilated input (DH = 2: data gradient of a stride-2 conv): a whole halo row is structural zeros whenever its
+            // virtual row index is odd, so for output row i only the tap rows kh with (vh0 + i + kh) even contribute --
+            // one of three for even output rows, two of three for odd ones.  The test is wave-uniform.
+            bool row_live[RPW][3];
+#pragma unroll
+            for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) row_live[i][kh] = DH == 1 || (((vh0 + (wave * RPW + i) * SH + kh) & (DH - 1)) == 0);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int kh = tap / 3, kw = tap % 3;
+                bool any_live = false;
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) any_live = any_live || row_live[i][kh];
+                if (!any_live) continue;
 #pragma unroll
                 for (int kk = 0; kk < CK; kk += KStep<T>::value) {
                     F af[RPW], bf[NB];
@@ -219,9 +231,11 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
                     for (int j = 0; j < NB; ++j)
                         bf[j] = *reinterpret_cast<const F*>(Ws + (long)((j * 32 + frow) * 9 + tap) * CKP + kk + fk);
 #pragma unroll
-                    for (int i = 0; i < RPW; ++i)
+                    for (int i = 0; i < RPW; ++i) {
+                        if (!row_live[i][kh]) continue;
 #pragma unroll
                         for (int j = 0; j < NB; ++j) mma32(acc[i][j], bf[j], af[i]);   // D[cout][pixel]
+                    }
                 }
             }
         }
