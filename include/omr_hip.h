@@ -44,8 +44,9 @@ int omr_colsum(int dtype, const void* dy, float* db, long M, int N, long ld, voi
  * p_bf16 (nullable) receives the bf16 compute copy of the updated parameters in the same pass. */
 int omr_adam(float* p, const float* g, float* m, float* v, void* p_bf16, long n, int step, float lr, float b1, float b2, float eps,
              float grad_scale, void* stream);
-/* greedy token pick: argmax(dim=-1) / topk(1) of the last-step logits (model.py:187,253) */
-int omr_argmax(const float* x, int n, long* idx_out, float* val_out, void* stream);
+/* greedy token pick: argmax(dim=-1) / topk(1) of the last-step logits (model.py:187,253), one row per decoded sample
+ * (x [rows][ld], first n columns); first-index tie rule */
+int omr_argmax(const float* x, int rows, int n, long ld, long* idx_out, float* val_out, void* stream);
 
 /* ---- normalisation ------------------------------------------------------------------------------------- */
 long omr_instnorm_workspace_bytes(int B, int C);

@@ -153,11 +153,14 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
-// ---------------------------------------------------------------- argmax over one fp32 vector (greedy decode, model.py:187)
-// First-max-index tie rule (torch.argmax).  Also returns top-1 value (model.py:253 topk(1)).
-__global__ void argmax_kernel(const float* __restrict__ x, int n, long* __restrict__ idx_out, float* __restrict__ val_out) {
+// ---------------------------------------------------------------- argmax over fp32 rows (greedy decode, model.py:187)
+// First-max-index tie rule (torch.argmax).  Also returns top-1 value (model.py:253 topk(1)).  One workgroup per row.
+__global__ void argmax_kernel(const float* __restrict__ x0, int n, long ld, long* __restrict__ idx_out0, float* __restrict__ val_out0) {
     __shared__ float sv[256];
     __shared__ int si[256];
+    const float* x = x0 + (long)blockIdx.x * ld;
+    long* idx_out = idx_out0 + blockIdx.x;
+    float* val_out = val_out0 ? val_out0 + blockIdx.x : nullptr;
     float best = -INFINITY; int bi = 0x7fffffff;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         float v = x[i];
@@ -275,9 +278,9 @@ extern "C" int omr_adam(float* p, const float* g, float* m, float* v, void* p_bf
     return OMR_OK;
 }
 
-extern "C" int omr_argmax(const float* x, int n, long* idx_out, float* val_out, void* stream) {
-    if (n <= 0) return OMR_ERR_ARG;
-    hipLaunchKernelGGL(argmax_kernel, 1, 256, 0, (hipStream_t)stream, x, n, idx_out, val_out);
+extern "C" int omr_argmax(const float* x, int rows, int n, long ld, long* idx_out, float* val_out, void* stream) {
+    if (n <= 0 || rows <= 0 || ld < n) return OMR_ERR_ARG;
+    hipLaunchKernelGGL(argmax_kernel, rows, 256, 0, (hipStream_t)stream, x, n, ld, idx_out, val_out);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }

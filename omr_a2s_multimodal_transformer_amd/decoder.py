@@ -251,17 +251,18 @@ class Decoder(nn.Module):
         if memory.dtype != dt:
             memory = K.cast(memory.contiguous(), dt)
         memory = memory.contiguous()
-        assert memory.shape[0] == 1, "Inference only supports batch_size = 1"
         layers = self.transformer_decoder.layers
         d = emb_w.shape[1]
+        B = memory.shape[0]                   # the reference decodes bs = 1; the cache is batched
         max_len = self.pos_1d.pe.shape[1]
         return dict(t=0, dtype=dt, d=d,
-                    cross_kv=[l.multihead_attn.project_kv(memory) for l in layers],             # [1,S,2d] per layer, once
-                    self_kv=torch.empty((len(layers), 1, max_len, 2 * d), dtype=dt, device=memory.device))
+                    cross_kv=[l.multihead_attn.project_kv(memory) for l in layers],             # [B,S,2d] per layer, once
+                    self_kv=torch.empty((len(layers), B, max_len, 2 * d), dtype=dt, device=memory.device))
 
     @torch.no_grad()
     def decode_step(self, token: torch.Tensor, st: dict) -> torch.Tensor:
-        """token int64 [1,1] -> fp32 logits [V] of the next position; advances the cache."""
+        """token int64 [B,1] -> fp32 logits of the next position ([V] for B = 1, else [B,V]); advances the cache.  Every
+        sample of the batch is at the same position t; rows are computed independently (same per-row arithmetic as bs = 1)."""
         t, d, dt = st["t"], st["d"], st["dtype"]
         if t >= self.pos_1d.pe.shape[1]:
             raise RuntimeError("decode_step beyond max_seq_len (positional-encoding table exhausted)")
@@ -269,8 +270,8 @@ class Decoder(nn.Module):
         lo = max(0, t - self.attn_window) if self.attn_window > 0 else 0     # banded causal mask = a key range (decoder.py:213-214)
         for li, layer in enumerate(self.transformer_decoder.layers):
             sa = layer.self_attn
-            qkv = Fn.linear(x, sa.in_proj_weight, sa.in_proj_bias)                                # [1,1,3d]
-            st["self_kv"][li, 0, t].copy_(qkv[0, 0, d:])
+            qkv = Fn.linear(x, sa.in_proj_weight, sa.in_proj_bias)                                # [B,1,3d]
+            st["self_kv"][li, :, t].copy_(qkv[:, 0, d:])
             o = Fn.AttentionFn.apply(qkv[..., :d], st["self_kv"][li, :, lo:t + 1], sa.num_heads, False, -1, None, None, None, 0.0, 0)
             x = Fn.AddLayerNormFn.apply(Fn.linear(o, sa.out_proj.weight, sa.out_proj.bias), x, layer.norm1.weight, layer.norm1.bias)
             ca = layer.multihead_attn.cross_attention(x, st["cross_kv"][li], None, False)
@@ -278,9 +279,10 @@ class Decoder(nn.Module):
             h = Fn.linear(x, layer.linear1.weight, layer.linear1.bias, relu=True)
             x = Fn.AddLayerNormFn.apply(Fn.linear(h, layer.linear2.weight, layer.linear2.bias), x, layer.norm3.weight, layer.norm3.bias)
         V = self.output_size
-        logits = Fn.linear(x, self.out_layer.weight, self.out_layer.bias, out_ld=K.round_up(V, 8))[0, 0]
+        logits = Fn.linear(x, self.out_layer.weight, self.out_layer.bias, out_ld=K.round_up(V, 8))[:, 0]         # [B,V]
         st["t"] = t + 1
-        return logits if logits.dtype == torch.float32 else K.cast(logits.contiguous(), torch.float32)
+        logits = logits if logits.dtype == torch.float32 else K.cast(logits.contiguous(), torch.float32)
+        return logits[0] if logits.shape[0] == 1 else logits
 
     def forward(self, tgt: torch.Tensor, memory: torch.Tensor, memory_len: Optional[torch.Tensor]) -> torch.Tensor:
         emb_w = self.embedding.weight

@@ -156,11 +156,13 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, 
 
 
 def argmax(x: Tensor) -> Tuple[Tensor, Tensor]:
+    """x fp32 [n] or [rows, n] (unit inner stride) -> (indices int64 [rows], top-1 values fp32 [rows])."""
     require_cuda(x)
-    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 1
-    idx = torch.empty(1, dtype=torch.int64, device=x.device)
-    val = torch.empty(1, dtype=torch.float32, device=x.device)
-    lib().call("omr_argmax", ptr(x), x.numel(), ptr(idx), ptr(val), cur_stream())
+    assert x.dtype == torch.float32 and x.dim() in (1, 2) and x.stride(-1) == 1
+    rows, n, ld = (1, x.numel(), x.numel()) if x.dim() == 1 else (x.shape[0], x.shape[1], x.stride(0))
+    idx = torch.empty(rows, dtype=torch.int64, device=x.device)
+    val = torch.empty(rows, dtype=torch.float32, device=x.device)
+    lib().call("omr_argmax", ptr(x), rows, n, ld, ptr(idx), ptr(val), cur_stream())
     return idx, val
 
 

@@ -172,6 +172,45 @@ class _Base(FlatModuleMixin, LightningModule):
         return yhat, probs
 
     @torch.no_grad()
+    def greedy_batch(self, memory: torch.Tensor, sync_every: int = 8) -> List[List[str]]:
+        """KV-cached greedy decode of B same-sized inputs at once (the reference loops bs = 1,
+        model.py:182-193).  Rows of the batch never interact, so each sequence equals what `_greedy` returns for that sample
+        alone (tests/test_model_gpu.py).  Inputs must share their size: the reference pads nothing at inference, and padding
+        would change the encoder features.  The host reads the chosen tokens back every `sync_every` steps only."""
+        B = memory.shape[0]
+        sos, eos = self.w2i[SOS_TOKEN], self.w2i[EOS_TOKEN]
+        tok = torch.full((B, 1), sos, dtype=torch.int64, device=memory.device)
+        state = self.decoder.init_decode(memory)
+        steps: List[torch.Tensor] = []
+        done = [False] * B
+        out: List[List[int]] = [[] for _ in range(B)]
+        consumed = 0
+
+        def drain():
+            nonlocal consumed
+            if consumed == len(steps):
+                return
+            host = torch.stack(steps[consumed:], dim=1).cpu().tolist()       # one device sync for the whole chunk
+            consumed = len(steps)
+            for b in range(B):
+                for t in host[b]:
+                    if not done[b]:
+                        out[b].append(t)
+                        done[b] = t == eos
+
+        for i in range(self.max_seq_len):
+            logits = self.decoder.decode_step(tok, state)
+            idx, _ = K.argmax((logits if logits.dim() == 2 else logits.view(1, -1)).contiguous())
+            steps.append(idx)
+            tok = idx.view(B, 1)
+            if (i + 1) % sync_every == 0:
+                drain()
+                if all(done):
+                    break
+        drain()
+        return [[self._i2w(t) for t in seq] for seq in out]
+
+    @torch.no_grad()
     def test_step(self, batch, batch_idx) -> None:
         self.validation_step(batch, batch_idx)
 

@@ -324,3 +324,32 @@ def test_decoder_bucket_is_final_when_backward_crosses_the_memory_boundary():
     final = m._flat.grad[b:e]
     assert final.abs().max() > 0
     assert torch.equal(probe.snap[1], final), "a decoder gradient changed after the bucket was handed to the all-reduce"
+
+
+@pytest.mark.parametrize("dtype,win", [("fp32", -1), ("fp32", 4), ("bf16", -1)])
+def test_batched_greedy_equals_per_sample_greedy(dtype, win):
+    """KV-cached greedy decode batched over same-sized samples gives, for every sample, exactly
+    the token sequence of the reference-style bs = 1 loop (rows of a batch never interact)."""
+    V = 30
+    m, w2i = make_transformer(V, ModelConfig(compute_dtype=dtype), 61, hw=(32, 96), max_seq=14, win=win)
+    m.eval()
+    xs = rnd((5, 1, 32, 96), 702).to(DEV)
+    mem = m.encode(xs)
+    batched = m.greedy_batch(mem, sync_every=3)
+    assert len(batched) == 5
+    for i in range(5):
+        single, _ = m._greedy(m.encode(xs[i:i + 1]))
+        assert batched[i] == single, (i, batched[i], single)
+    # the rows differ (a random-init model may still pick the same tokens): the batched step reproduces each sample's own
+    # next-token logits to the bit, so no row can have been mixed up with another
+    sos = w2i["<sos>"]
+    st_b = m.decoder.init_decode(mem)
+    st_1 = [m.decoder.init_decode(mem[i:i + 1].contiguous()) for i in range(5)]
+    tok = torch.full((5, 1), sos, dtype=torch.int64, device=DEV)
+    for _ in range(3):
+        lb = m.decoder.decode_step(tok, st_b)
+        rows = [m.decoder.decode_step(tok[i:i + 1], st_1[i]) for i in range(5)]
+        for i in range(5):
+            assert torch.equal(lb[i], rows[i])
+        assert not torch.equal(lb[0], lb[1])
+        tok = lb.argmax(dim=1, keepdim=True)
