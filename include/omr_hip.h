@@ -47,6 +47,9 @@ int omr_adam(float* p, const float* g, float* m, float* v, void* p_bf16, long n,
 /* greedy token pick: argmax(dim=-1) / topk(1) of the last-step logits (model.py:187,253), one row per decoded sample
  * (x [rows][ld], first n columns); first-index tie rule */
 int omr_argmax(const float* x, int rows, int n, long ld, long* idx_out, float* val_out, void* stream);
+/* beam-search expansion (BASELINE config C5; an extension: the reference decodes greedily): per row the k largest
+ * log_softmax values and their token ids, same tie rule as omr_argmax, idx_out / val_out [rows][k] */
+int omr_topk_logprob(const float* x, int rows, int n, long ld, int k, long* idx_out, float* val_out, void* stream);
 
 /* ---- normalisation ------------------------------------------------------------------------------------- */
 long omr_instnorm_workspace_bytes(int B, int C);

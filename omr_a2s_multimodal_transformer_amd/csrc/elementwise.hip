@@ -178,6 +178,52 @@ __global__ void argmax_kernel(const float* __restrict__ x0, int n, long ld, long
     if (threadIdx.x == 0) { idx_out[0] = si[0]; if (val_out) val_out[0] = sv[0]; }
 }
 
+// ---------------------------------------------------------------- top-k log-probabilities per row (beam search)
+// out_val[row][j] = log_softmax(x[row])[out_idx[row][j]], j-th largest, ties broken towards the smaller index (so k = 1 is
+// argmax_kernel's pick).  One workgroup per row: a max / sum-exp pass, then k selection passes over the candidates that
+// come after the previous pick in (value descending, index ascending) order.
+__global__ void topk_logprob_kernel(const float* __restrict__ x0, int n, long ld, int k, long* __restrict__ idx_out, float* __restrict__ val_out) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const float* x = x0 + (long)blockIdx.x * ld;
+    const int tid = threadIdx.x;
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += 256) mx = fmaxf(mx, x[i]);
+    sv[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) sv[tid] = fmaxf(sv[tid], sv[tid + o]); __syncthreads(); }
+    mx = sv[0];
+    __syncthreads();
+    float se = 0.f;
+    for (int i = tid; i < n; i += 256) se += expf(x[i] - mx);
+    sv[tid] = se;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) sv[tid] += sv[tid + o]; __syncthreads(); }
+    const float lse = mx + logf(sv[0]);
+    __syncthreads();
+    float last_v = INFINITY; int last_i = -1;
+    for (int j = 0; j < k; ++j) {
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int i = tid; i < n; i += 256) {
+            const float v = x[i];
+            const bool cand = v < last_v || (v == last_v && i > last_i);
+            if (cand && (v > best || (v == best && i < bi))) { best = v; bi = i; }
+        }
+        sv[tid] = best; si[tid] = bi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                const float v2 = sv[tid + o]; const int i2 = si[tid + o];
+                if (v2 > sv[tid] || (v2 == sv[tid] && i2 < si[tid])) { sv[tid] = v2; si[tid] = i2; }
+            }
+            __syncthreads();
+        }
+        last_v = sv[0]; last_i = si[0];
+        if (tid == 0) { idx_out[(long)blockIdx.x * k + j] = last_i; val_out[(long)blockIdx.x * k + j] = last_v - lse; }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL)                         \
@@ -274,6 +320,13 @@ extern "C" int omr_adam(float* p, const float* g, float* m, float* v, void* p_bf
     double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     hipLaunchKernelGGL(adam_kernel, ew_grid(n), EW_BLOCK, 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16, n, (float)(lr / bc1), b1, b2, eps,
                        (float)(1.0 / sqrt(bc2)), grad_scale);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_topk_logprob(const float* x, int rows, int n, long ld, int k, long* idx_out, float* val_out, void* stream) {
+    if (n <= 0 || rows <= 0 || ld < n || k <= 0 || k > n || !idx_out || !val_out) return OMR_ERR_ARG;
+    hipLaunchKernelGGL(topk_logprob_kernel, rows, 256, 0, (hipStream_t)stream, x, n, ld, k, idx_out, val_out);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }

@@ -166,6 +166,16 @@ def argmax(x: Tensor) -> Tuple[Tensor, Tensor]:
     return idx, val
 
 
+def topk_logprob(x: Tensor, k: int) -> Tuple[Tensor, Tensor]:
+    """x fp32 [rows, n] -> (token ids int64 [rows, k], log-probabilities fp32 [rows, k]), best first."""
+    require_cuda(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and 0 < k <= x.shape[1]
+    idx = torch.empty((x.shape[0], k), dtype=torch.int64, device=x.device)
+    val = torch.empty((x.shape[0], k), dtype=torch.float32, device=x.device)
+    lib().call("omr_topk_logprob", ptr(x), x.shape[0], x.shape[1], x.stride(0), k, ptr(idx), ptr(val), cur_stream())
+    return idx, val
+
+
 # ------------------------------------------------------------------------------------------------ normalisation
 
 def _in_ws(B: int, C: int, device) -> Tensor:

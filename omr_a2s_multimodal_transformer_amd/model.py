@@ -211,6 +211,51 @@ class _Base(FlatModuleMixin, LightningModule):
         return [[self._i2w(t) for t in seq] for seq in out]
 
     @torch.no_grad()
+    def beam_search(self, memory: torch.Tensor, beam: int = 4) -> Tuple[List[str], float]:
+        """Beam-search decode of ONE input (BASELINE config C5; an extension -- the reference only decodes greedily).  The
+        `beam` hypotheses are the batch rows of the KV-cached step; scores are sums of log-probabilities (no length
+        normalisation); beam = 1 reproduces `_greedy` token for token.  Returns (words incl. <eos> if reached, score)."""
+        assert memory.shape[0] == 1 and beam >= 1
+        sos, eos = self.w2i[SOS_TOKEN], self.w2i[EOS_TOKEN]
+        dev = memory.device
+        state = self.decoder.init_decode(memory)
+        state["cross_kv"] = [kv.expand(beam, -1, -1) for kv in state["cross_kv"]]      # every hypothesis reads the same memory K|V
+        L, _, max_len, w = state["self_kv"].shape
+        state["self_kv"] = torch.empty((L, beam, max_len, w), dtype=state["self_kv"].dtype, device=dev)
+        tok = torch.full((beam, 1), sos, dtype=torch.int64, device=dev)
+        scores = [0.0] + [float("-inf")] * (beam - 1)       # only the first row is a real hypothesis before the first step
+        seqs: List[List[int]] = [[] for _ in range(beam)]
+        best_done: Tuple[float, Optional[List[int]]] = (float("-inf"), None)
+        exhausted = True                                     # the loop ran out of positions with hypotheses still alive
+        for _ in range(self.max_seq_len):
+            logits = self.decoder.decode_step(tok, state)
+            idx, val = K.topk_logprob((logits if logits.dim() == 2 else logits.view(1, -1)).contiguous(), beam)
+            idx_h, val_h = idx.cpu().tolist(), val.cpu().tolist()
+            cands = [(scores[b] + val_h[b][j], b, idx_h[b][j]) for b in range(beam) if scores[b] > float("-inf") for j in range(beam)]
+            cands.sort(key=lambda c: (-c[0], c[1], c[2]))
+            parents, new_tok, new_scores, new_seqs = [], [], [], []
+            for sc, b, t in cands:
+                if t == eos:
+                    if sc > best_done[0]:
+                        best_done = (sc, seqs[b] + [t])
+                    continue
+                parents.append(b); new_tok.append(t); new_scores.append(sc); new_seqs.append(seqs[b] + [t])
+                if len(parents) == beam:
+                    break
+            if not parents or new_scores[0] <= best_done[0]:        # scores only fall: no live hypothesis can overtake the best finished one
+                exhausted = False
+                break
+            while len(parents) < beam:                                # pad with dead rows
+                parents.append(parents[0]); new_tok.append(new_tok[0]); new_scores.append(float("-inf")); new_seqs.append([])
+            pidx = torch.tensor(parents, dtype=torch.int64, device=dev)
+            state["self_kv"] = state["self_kv"].index_select(1, pidx)
+            tok = torch.tensor(new_tok, dtype=torch.int64, device=dev).view(beam, 1)
+            scores, seqs = new_scores, new_seqs
+        if exhausted and scores[0] > best_done[0]:
+            best_done = (scores[0], seqs[0])                          # ran out of length: the best unfinished hypothesis wins
+        return [self._i2w(t) for t in best_done[1]], best_done[0]
+
+    @torch.no_grad()
     def test_step(self, batch, batch_idx) -> None:
         self.validation_step(batch, batch_idx)
 

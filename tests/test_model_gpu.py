@@ -353,3 +353,29 @@ def test_batched_greedy_equals_per_sample_greedy(dtype, win):
             assert torch.equal(lb[i], rows[i])
         assert not torch.equal(lb[0], lb[1])
         tok = lb.argmax(dim=1, keepdim=True)
+
+
+@pytest.mark.parametrize("win", [-1, 4])
+def test_beam_search_beam1_is_greedy_and_wider_beams_do_not_score_lower(win):
+    """Beam search (BASELINE C5 extension): beam = 1 reproduces the greedy tokens; a wider beam never returns a lower score."""
+    V = 30
+    m, w2i = make_transformer(V, ModelConfig(), 61, hw=(32, 96), max_seq=14, win=win)
+    m.eval()
+    mem = m.encode(rnd((1, 1, 32, 96), 703).to(DEV))
+    greedy, _ = m._greedy(mem)
+    seq1, score1 = m.beam_search(mem, beam=1)
+    assert seq1 == greedy
+    seq4, score4 = m.beam_search(mem, beam=4)
+    assert score4 >= score1 - 1e-5 and len(seq4) >= 1
+
+
+def test_topk_logprob_matches_torch():
+    from omr_a2s_multimodal_transformer_amd import kernels as K
+    x = (rnd((5, 6997), 704) * 8 - 4).to(DEV)
+    x[2, 100] = x[2, 7]                      # a tie: the smaller index must come first
+    idx, val = K.topk_logprob(x, 6)
+    ref = torch.log_softmax(x, dim=1)
+    rv, ri = torch.sort(ref, dim=1, descending=True, stable=True)
+    assert torch.equal(idx, ri[:, :6])
+    torch.testing.assert_close(val, rv[:, :6], rtol=1e-5, atol=1e-5)
+    assert torch.equal(K.argmax(x)[0], idx[:, 0])
