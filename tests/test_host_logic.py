@@ -102,3 +102,38 @@ def test_product_has_no_cpu_fallback():
     from omr_a2s_multimodal_transformer_amd import kernels as K
     with pytest.raises(RuntimeError, match="no CPU fallback|GPU only"):
         K.add(torch.zeros(4), torch.zeros(4))
+
+
+def test_split_multimodal_checkpoint_into_unimodal_checkpoints(tmp_path):
+    """the multimodal -> unimodal split (reference src/utils/split_multimodal_ckpt.py) on a
+    synthetic Lightning-layout checkpoint: state-dict keys become exactly the unimodal Transformer's, hyper-parameters are
+    renamed, the ModelCheckpoint callback points at the new file, tensors are untouched."""
+    import torch
+    from omr_a2s_multimodal_transformer_amd import synthetic as syn
+    from omr_a2s_multimodal_transformer_amd.ckpt_tools import split_both_ckpt_in_two
+
+    V = 40
+    sd = syn.seeded_state_dict(syn.multimodal_shapes(V, "attn_both", d=64, ff=64, layers=2), 5)
+    best = str(tmp_path / "run" / "best.ckpt")
+    ck = {"state_dict": sd, "epoch": 3,
+          "hyper_parameters": dict(max_img_height=64, max_img_width=128, max_audio_height=48, max_audio_width=256, max_seq_len=20,
+                                   mixer_type="attn_both", teacher_forcing_modality_prob=0.5, attn_window=-1),
+          "callbacks": {"ModelCheckpoint{'monitor': 'val_sym-er'}": {"best_model_path": best, "best_model_score": 0.25,
+                                                                    "kth_best_model_path": best, "best_k_models": {best: 0.25}}}}
+    src = str(tmp_path / "mm.ckpt")
+    torch.save(ck, src)
+    img_path, aud_path = split_both_ckpt_in_two(src)
+    assert img_path.endswith("mm_only_image_distorted.ckpt") and aud_path.endswith("mm_only_audio.ckpt")
+    uni_keys = set(syn.transformer_shapes(V, 64, 64, 2).keys())
+    for path, mod, h, w, suffix in ((img_path, "image", 64, 128, "image_distorted"), (aud_path, "audio", 48, 256, "audio")):
+        one = torch.load(path, weights_only=True)
+        got = {k for k in one["state_dict"] if not k.endswith("pe") and not k.endswith("pe_hwc")}
+        assert got == {k for k in uni_keys if not k.endswith("pe")}, (sorted(got ^ uni_keys))
+        assert torch.equal(one["state_dict"]["encoder.conv_blocks.0.conv1.weight"], sd[f"{mod}_encoder.conv_blocks.0.conv1.weight"])
+        assert torch.equal(one["state_dict"]["decoder.out_layer.weight"], sd["decoder.out_layer.weight"])
+        hp = one["hyper_parameters"]
+        assert hp["max_input_height"] == h and hp["max_input_width"] == w and hp["max_seq_len"] == 20
+        assert not any(k in hp for k in ("mixer_type", "teacher_forcing_modality_prob", "max_img_height", "max_audio_width"))
+        cb = next(iter(one["callbacks"].values()))
+        assert cb["best_model_path"].endswith(f"best_only_{suffix}.ckpt") and cb["best_k_models"] == {cb["best_model_path"]: 0.25}
+        assert one["epoch"] == 3
