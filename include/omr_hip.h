@@ -47,6 +47,11 @@ int omr_adam(float* p, const float* g, float* m, float* v, void* p_bf16, long n,
 /* greedy token pick: argmax(dim=-1) / topk(1) of the last-step logits (model.py:187,253), one row per decoded sample
  * (x [rows][ld], first n columns); first-index tie rule */
 int omr_argmax(const float* x, int rows, int n, long ld, long* idx_out, float* val_out, void* stream);
+/* audio front end (preprocessing.py:17-30): after the windowed DFT -- ONE omr_gemm of the centred,
+ * hop-strided frames (lda = hop) against the Hann-weighted [cos | -sin] basis of the kept bins -- spec [frames][2*bins] holds
+ * (re | im); this turns it into the reference's normalised log-spectrogram out [bins][frames] =
+ * amplitude_to_db(|S|, ref=max, top_db=80) / 80 + 1.  spec is overwritten (magnitudes); max_ws: 4 bytes of device scratch. */
+int omr_log_stft_post(float* spec, long frames, int bins, unsigned* max_ws, float* out, void* stream);
 /* beam-search expansion (BASELINE config C5; an extension: the reference decodes greedily): per row the k largest
  * log_softmax values and their token ids, same tie rule as omr_argmax, idx_out / val_out [rows][k] */
 int omr_topk_logprob(const float* x, int rows, int n, long ld, int k, long* idx_out, float* val_out, void* stream);

@@ -224,6 +224,35 @@ __global__ void topk_logprob_kernel(const float* __restrict__ x0, int n, long ld
     }
 }
 
+// ---------------------------------------------------------------- log-STFT post-processing (audio front end)
+// spec [frames][2*bins] = (re | im) halves of the windowed DFT (one fp32 GEMM against the Hann-weighted cos / -sin basis).
+// Pass 1: magnitude in place of `re` and the global maximum (non-negative floats order like their bit patterns).
+__global__ void stft_mag_max_kernel(float* __restrict__ spec, long frames, int bins, unsigned* __restrict__ maxbits) {
+    const long n = frames * bins;
+    float mx = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long f = i / bins; const int k = (int)(i % bins);
+        const float re = spec[f * 2 * bins + k], im = spec[f * 2 * bins + bins + k];
+        const float m = sqrtf(re * re + im * im);
+        spec[f * 2 * bins + k] = m;
+        mx = fmaxf(mx, m);
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) atomicMax(maxbits, __float_as_uint(mx));
+}
+// Pass 2: out[bin][frame] = max(20 log10(max(amin, m)) - 20 log10(max(amin, max)), -top_db) / top_db + 1
+// (librosa.amplitude_to_db(ref=np.max) with its default top_db = 80, then the reference's /80 + 1; preprocessing.py:27-28)
+__global__ void stft_db_kernel(const float* __restrict__ spec, long frames, int bins, const unsigned* __restrict__ maxbits, float* __restrict__ out) {
+    const float amin = 1e-5f, top_db = 80.f;
+    const float ref_db = 20.f * log10f(fmaxf(amin, __uint_as_float(*maxbits)));
+    const long n = frames * bins;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i / frames); const long f = i % frames;       // output-major: coalesced stores
+        const float db = fmaxf(20.f * log10f(fmaxf(amin, spec[f * 2 * bins + k])) - ref_db, -top_db);
+        out[i] = db / top_db + 1.f;
+    }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL)                         \
@@ -320,6 +349,16 @@ extern "C" int omr_adam(float* p, const float* g, float* m, float* v, void* p_bf
     double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     hipLaunchKernelGGL(adam_kernel, ew_grid(n), EW_BLOCK, 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16, n, (float)(lr / bc1), b1, b2, eps,
                        (float)(1.0 / sqrt(bc2)), grad_scale);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_log_stft_post(float* spec, long frames, int bins, unsigned* max_ws, float* out, void* stream) {
+    if (frames <= 0 || bins <= 0 || !spec || !max_ws || !out) return OMR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(max_ws, 0, sizeof(unsigned), s) != hipSuccess) return OMR_ERR_LAUNCH;
+    hipLaunchKernelGGL(stft_mag_max_kernel, ew_grid(frames * bins), EW_BLOCK, 0, s, spec, frames, bins, max_ws);
+    hipLaunchKernelGGL(stft_db_kernel, ew_grid(frames * bins), EW_BLOCK, 0, s, (const float*)spec, frames, bins, (const unsigned*)max_ws, out);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }

@@ -401,3 +401,29 @@ def collate_unimodal(batch, pad_value: float):
     y_in = torch.stack([F.pad(t[:-1], (0, ml - (len(t) - 1))) for t in ys]).long()
     y_out = torch.stack([F.pad(t[1:], (0, ml - (len(t) - 1))) for t in ys]).long()
     return x, xl, y_in, y_out
+
+
+def log_stft(y, n_fft: int = 2048, hop: int = 512, sr: int = 22050, fmax: float = 2093.0):
+    """Spectrogram front end of the audio branch (reference src/data/preprocessing.py:17-30) for a signal that is already at
+    22 050 Hz: librosa.stft(hop_length=512, win_length=2048, window="hann") -- centred frames, zero ("constant") padding of
+    n_fft//2 samples at both ends, periodic Hann window, 1 + len(y)//hop frames -- keep the bins with frequency
+    k*sr/n_fft <= 2093 Hz (195 of them), amplitude_to_db(|S|, ref=max) = 20 log10(max(1e-5, |S|)) - 20 log10(max(1e-5, max|S|))
+    clipped at 80 dB below its own maximum, then /80 + 1.  Returns float32 [195, frames].
+    PARITY UNPINNED: librosa is not installed in the build container, so this restates librosa's documented algorithm
+    (librosa 0.10 core/spectrum.py: stft, amplitude_to_db, power_to_db) without a fixture from the reference itself; the
+    resampling step (librosa.resample) is not restated."""
+    import numpy as np
+    y = np.asarray(y, dtype=np.float64)
+    pad = n_fft // 2
+    yp = np.pad(y, (pad, pad), mode="constant")
+    n_frames = 1 + len(y) // hop
+    n = np.arange(n_fft)
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)                 # scipy.signal.get_window("hann", n_fft, fftbins=True)
+    frames = np.stack([yp[i * hop:i * hop + n_fft] * win for i in range(n_frames)], axis=1)     # [n_fft, frames]
+    spec = np.fft.rfft(frames, axis=0)
+    keep = (np.arange(n_fft // 2 + 1) * sr / n_fft) <= fmax
+    mag = np.abs(spec[keep])
+    amin = 1e-5
+    db = 20.0 * np.log10(np.maximum(amin, mag)) - 20.0 * np.log10(max(amin, mag.max()))
+    db = np.maximum(db, db.max() - 80.0)
+    return (db / 80.0 + 1.0).astype(np.float32)

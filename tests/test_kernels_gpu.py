@@ -2,6 +2,8 @@
 fp32 runs are held to ~1e-4 (exact-f32 MFMA chain, different summation order); bf16 runs to bf16 rounding."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -468,3 +470,21 @@ def test_conv3x3_fused_dropout_and_instnorm_reductions(dtype, channel_mode):
     assert torch.equal(dxh, dxh_ref)
     dx = k.instnorm_bwd_apply(dxh, y, mean, rstd, ws2, relu_mask=True, relu_scale=2.0)
     torch.testing.assert_close(dx.float(), dx_ref.float(), **tol(dtype, 2))
+
+
+# ------------------------------------------------------------------------------------------------ audio front end
+
+@pytest.mark.parametrize("n", [22050 * 3 + 137, 5000])
+def test_log_stft_matches_oracle(n):
+    """GPU log-STFT (one fp32 GEMM + dB kernels) vs the numpy restatement of the reference's librosa pipeline
+    (preprocessing.py:17-30).  librosa is absent in this image: parity with librosa itself is unpinned (see oracle)."""
+    from omr_a2s_multimodal_transformer_amd import audio
+    t = torch.arange(n, dtype=torch.float64) / 22050
+    g = torch.Generator().manual_seed(3)
+    y = (0.6 * torch.sin(2 * math.pi * 440 * t) + 0.3 * torch.sin(2 * math.pi * 1318.5 * t * (1 + 0.01 * t)) + 0.02 * torch.randn(n, generator=g, dtype=torch.float64)).float()
+    ref = R.log_stft(y.numpy())
+    out = audio.log_stft(y.to(dev()))
+    assert tuple(out.shape) == (1, 195, 1 + n // 512) and ref.shape == tuple(out.shape[1:])
+    got = out[0].cpu().numpy()
+    assert got.min() >= 0.0 and got.max() == pytest.approx(1.0, abs=1e-6)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-3)
