@@ -137,3 +137,18 @@ def test_split_multimodal_checkpoint_into_unimodal_checkpoints(tmp_path):
         cb = next(iter(one["callbacks"].values()))
         assert cb["best_model_path"].endswith(f"best_only_{suffix}.ckpt") and cb["best_k_models"] == {cb["best_model_path"]: 0.25}
         assert one["epoch"] == 3
+
+
+def test_oracle_log_stft_properties():
+    """oracle.log_stft (restated librosa pipeline, parity unpinned -- librosa absent): shape contract of preprocessing.py:13-30,
+    range [0, 1] with the global peak at exactly 1, and a pure tone landing in the right frequency bin."""
+    import numpy as np
+    from oracle import ref_cpu as R
+    sr, n = 22050, 22050 * 2 + 100
+    y = np.sin(2 * np.pi * 1000.0 * np.arange(n) / sr)
+    s = R.log_stft(y)
+    assert s.shape == (195, 1 + n // 512) and s.dtype == np.float32
+    assert s.min() >= 0.0 and s.max() == 1.0
+    assert abs(int(np.argmax(s[:, s.shape[1] // 2])) - round(1000.0 * 2048 / sr)) <= 1
+    silent = R.log_stft(np.zeros(4096))
+    assert np.all(silent == 1.0)          # amplitude_to_db of all-amin input: 0 dB everywhere -> 1.0 after /80 + 1
