@@ -1,3 +1,4 @@
+"""Per-kernel time summary of a rocprofv3 --kernel-trace --stats --output-format csv run: python tools/prof_summary.py <dir> <steps+warmup> <rows>."""
 import csv, glob, sys
 d = sys.argv[1]; steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 f = glob.glob(d + '/*/*_kernel_stats.csv')[0]
