@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
         }
 
         // ---- epilogue
+        const float oscale = a.mask ? a.mask_scale : 1.f;
         __syncthreads();                              // every wave is done reading Xs: Os aliases it
 #pragma unroll
         for (int j = 0; j < NB; ++j)
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
                     for (int e = 0; e < 4; ++e) {
                         float v = acc[i][j][4 * g + e] + bq[e];
                         if (a.relu) v = fmaxf(v, 0.f);
-                        o[e] = from_f32<T>(v);
+                        o[e] = from_f32<T>(v * oscale);     // the epilogue mask's 1/(1-p) rides here in fp32: the store loop only selects
                     }
                     *reinterpret_cast<T4*>(orow + 8 * g) = o;
                 }
@@ -281,10 +282,15 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
                     }
                 }
             }
-            if (Mk) {
-                const F m = *reinterpret_cast<const F*>(Mk + o);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] = from_f32<T>(to_f32(m[e]) > 0.f ? to_f32(v[e]) * a.mask_scale : 0.f);
+            if (Mk) {      // keep where the saved activation is > 0: for bf16 and fp32 alike that is "bit pattern > 0 as a signed integer"
+                typedef typename std::conditional<sizeof(T) == 2, short, int>::type I;
+                typedef __attribute__((ext_vector_type(VEC))) I IV;
+                const IV m = *reinterpret_cast<const IV*>(Mk + o);
+                const IV keep = m > (I)0;                       // lanes of -1 / 0
+                IV bits;
+                __builtin_memcpy(&bits, &v, sizeof(bits));
+                bits &= keep;
+                __builtin_memcpy(&v, &bits, sizeof(bits));
             }
             *reinterpret_cast<F*>(Y + o) = v;
             if constexpr (EPI == 1) {
