@@ -59,7 +59,7 @@ struct ConvArgs {
 // EPI selects the fused-epilogue code that is compiled in (keeps the plain kernel's register footprint small):
 //   0 plain | 1 forward extras: MixDropout + InstanceNorm statistics of the output | 2 backward extras: InstanceNorm-backward sums
 template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, bool SINGLE, int EPI>
-__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (SINGLE && NT == 32) ? 3 : 2) void conv3x3_mfma_kernel(ConvArgs a) {
     typedef typename Frag<T>::type F;
     typedef __attribute__((ext_vector_type(4))) T T4;
     constexpr int VEC = Frag<T>::N;
@@ -149,11 +149,75 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
             srs[e] = n < a.COUT ? a.stat_rstd[(long)b * a.COUT + n] : 1.f;
         }
     }
+    // Staging registers.  PF (every multi-chunk variant: those are LDS-limited to two workgroups per CU, so the registers are
+    // free): the halo and weight chunks of the NEXT (tile, channel chunk) are loaded into registers before the MFMAs of the
+    // current one and written to LDS after them, so a chunk's global latency hides behind a chunk's math instead of a barrier.
+    constexpr bool PF = true;
+    constexpr int XR = (NPIX + 255) / 256;
+    constexpr int WNCH = NT * 9 * CPP, WR = SINGLE ? 1 : (WNCH + 255) / 256;
+    F xv[XR][CPP], wv[WR];
+    unsigned xok = 0;                                 // bit r: halo pixel of round r is a real input pixel
+    const T* X = (const T*)a.x + (long)b * a.Hr * a.Wr * a.CIN;
+    auto load_x = [&](int rem, int c0) {
+        const int th = rem / a.tiles_w, tw = rem - th * a.tiles_w;
+        const int vh0 = th * TH * SH - 1, vw0 = tw * TW * SW - 1;   // virtual (dilated) input origin of the halo
+        xok = 0;
+#pragma unroll
+        for (int r = 0; r < XR; ++r) {
+            const int pix = tid + r * 256;
+            const int il = pix / IW, jl = pix - il * IW;
+            const int vh = vh0 + il, vw = vw0 + jl;
+            const bool ok = pix < NPIX && vh >= 0 && vh < Hv && vw >= 0 && vw < Wv && (vh & (DH - 1)) == 0 && (vw & (DW - 1)) == 0;
+            const T* src = X + ((long)(vh >> (DH >> 1)) * a.Wr + (vw >> (DW >> 1))) * a.CIN + c0;
+#pragma unroll
+            for (int k = 0; k < CPP; ++k) {
+                xv[r][k] = frag_zero<T>();
+                if (ok) xv[r][k] = *reinterpret_cast<const F*>(src + k * VEC);
+            }
+            xok |= (unsigned)ok << r;
+        }
+    };
+    auto store_x = [&](int c0) {
+#pragma unroll
+        for (int r = 0; r < XR; ++r) {
+            const int pix = tid + r * 256;
+            if (a.mean && ((xok >> r) & 1)) {
+#pragma unroll
+                for (int k = 0; k < CPP; ++k)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const int ch = b * a.CIN + c0 + k * VEC + e;
+                        xv[r][k][e] = from_f32<T>((to_f32(xv[r][k][e]) - a.mean[ch]) * a.rstd[ch]);
+                    }
+            }
+            if (pix < NPIX)
+#pragma unroll
+                for (int k = 0; k < CPP; ++k) *reinterpret_cast<F*>(Xs + (long)pix * CKP + k * VEC) = xv[r][k];
+        }
+    };
+    auto load_w = [&](int c0) {
+#pragma unroll
+        for (int r = 0; r < WR; ++r) {
+            const int c = tid + r * 256, row = c / CPP, kc = (c % CPP) * VEC, n = n0 + row / 9;
+            wv[r] = frag_zero<T>();
+            if (c < WNCH && n < a.COUT) wv[r] = *reinterpret_cast<const F*>(W + ((long)n * 9 + row % 9) * a.CIN + c0 + kc);
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int r = 0; r < WR; ++r) {
+            const int c = tid + r * 256, row = c / CPP, kc = (c % CPP) * VEC;
+            if (c < WNCH) *reinterpret_cast<F*>(Ws + (long)row * CKP + kc) = wv[r];
+        }
+    };
+    if constexpr (PF) {
+        if ((int)blockIdx.x < tiles_per_img) { load_x(blockIdx.x, 0); load_w(0); }
+    }
+
     for (int rem = blockIdx.x; rem < tiles_per_img; rem += gridDim.x) {
         const int th = rem / a.tiles_w, tw = rem - th * a.tiles_w;
         const int oh0 = th * TH, ow0 = tw * TW;
-        const int vh0 = oh0 * SH - 1, vw0 = ow0 * SW - 1;           // virtual (dilated) input origin of the halo
-        const T* X = (const T*)a.x + (long)b * a.Hr * a.Wr * a.CIN;
+        const int vh0 = oh0 * SH - 1;
 
         f32x16 acc[RPW][NB];
 #pragma unroll
@@ -168,41 +232,15 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
             // ---- stage the input halo: thread = one halo pixel per round (ONE bounds test + address for its CPP chunks:
             //      measured 30 % faster than chunk-granular staging on the 16/32-channel layers, which are VALU-limited);
             //      all loads of all rounds are issued before the first LDS store
-            {
-                constexpr int ROUNDS = (NPIX + 255) / 256;
-                F v[ROUNDS][CPP];
-#pragma unroll
-                for (int r = 0; r < ROUNDS; ++r) {
-                    const int pix = tid + r * 256;
-                    const int il = pix / IW, jl = pix - il * IW;
-                    const int vh = vh0 + il, vw = vw0 + jl;
-                    const bool ok = pix < NPIX && vh >= 0 && vh < Hv && vw >= 0 && vw < Wv && (vh & (DH - 1)) == 0 && (vw & (DW - 1)) == 0;
-                    const T* src = X + ((long)(vh >> (DH >> 1)) * a.Wr + (vw >> (DW >> 1))) * a.CIN + c0;
-#pragma unroll
-                    for (int k = 0; k < CPP; ++k) {
-                        v[r][k] = frag_zero<T>();
-                        if (ok) v[r][k] = *reinterpret_cast<const F*>(src + k * VEC);
-                    }
-                    if (ok && a.mean) {
-#pragma unroll
-                        for (int k = 0; k < CPP; ++k)
-#pragma unroll
-                            for (int e = 0; e < VEC; ++e) {
-                                const int ch = b * a.CIN + c0 + k * VEC + e;
-                                v[r][k][e] = from_f32<T>((to_f32(v[r][k][e]) - a.mean[ch]) * a.rstd[ch]);
-                            }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < ROUNDS; ++r) {
-                    const int pix = tid + r * 256;
-                    if (pix < NPIX)
-#pragma unroll
-                        for (int k = 0; k < CPP; ++k) *reinterpret_cast<F*>(Xs + (long)pix * CKP + k * VEC) = v[r][k];
-                }
-            }
-            if (!single) stage_weights(c0);
+            if constexpr (!PF) load_x(rem, c0);
+            store_x(c0);
+            if constexpr (!SINGLE) store_w();
             __syncthreads();
+            if constexpr (PF) {
+                int nc0 = c0 + CK, nrem = rem;
+                if (nc0 >= a.CIN) { nc0 = 0; nrem = rem + gridDim.x; }
+                if (nrem < tiles_per_img) { load_x(nrem, nc0); load_w(nc0); }
+            }
             // ---- nine shifted GEMMs out of LDS
             // Zero-dilated input (DH = 2: data gradient of a stride-2 conv): a whole halo row is structural zeros whenever its
             // virtual row index is odd, so for output row i only the tap rows kh with (vh0 + i + kh) even contribute --
