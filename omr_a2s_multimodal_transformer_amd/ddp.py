@@ -23,6 +23,8 @@ import torch
 import torch.distributed as dist
 from torch.autograd import Function
 
+from .runtime import WgradStream
+
 
 class GradReducer:
     def __init__(self, flat, process_group=None, buckets: Optional[Sequence[Tuple[int, int]]] = None, async_stream: bool = True):
@@ -45,6 +47,7 @@ class GradReducer:
         if self.world == 1 or self.done[i]:
             return
         self.done[i] = True
+        WgradStream.join()                     # weight gradients issued on the side stream belong to the bucket too
         b, e = self.buckets[i]
         view = self.flat.grad[b:e]
         if self.use_stream:

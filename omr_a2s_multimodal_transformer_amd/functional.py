@@ -19,6 +19,7 @@ import torch
 from torch.autograd import Function
 
 from . import kernels as K
+from .runtime import WgradStream
 
 Tensor = torch.Tensor
 
@@ -79,7 +80,7 @@ class Conv3x3Fn(Function):
         g = gy.contiguous()
         if relu and mask_own:
             g = K.relu_bwd(g, y, own_scale)        # y is the stored (dropped) output: (y > 0) * 1/(1-p) is ReLU + dropout backward
-        K.conv3x3_wgrad(x, g, weight.omr_grad, stride=stride, in_stats=stats, db=bias.omr_grad)
+        K.conv3x3_wgrad(x, g, weight.omr_grad, stride=stride, in_stats=stats, db=bias.omr_grad)   # fills every CU's LDS: nothing to gain on the side stream (measured)
         dx = None
         if ctx.needs_input_grad[0]:
             wd = K.conv3x3_weight_flip(wt(weight, x.dtype))
@@ -112,7 +113,7 @@ class DwConv3x3Fn(Function):
         (x,) = ctx.saved_tensors
         weight, bias, stats = ctx.weight, ctx.bias, ctx.stats
         g = gy.contiguous()
-        K.dwconv3x3_wgrad(x, g, weight.omr_grad, bias.omr_grad, in_stats=stats)
+        WgradStream.run(lambda: K.dwconv3x3_wgrad(x, g, weight.omr_grad, bias.omr_grad, in_stats=stats), x, g, *(stats or ()))
         dx = None
         if ctx.needs_input_grad[0]:
             w = wt(weight, x.dtype)
@@ -171,7 +172,8 @@ class LinearFn(Function):
         if relu and mask_own:
             g2 = K.relu_bwd(g2.contiguous(), y2, own_scale)     # y2 is the stored (dropped) output: ReLU + dropout backward in one mask
         M = g2.shape[0]
-        K.gemm(g2, x2, trans_a=True, trans_b=True, out=gw, accumulate=True, split_k=split_k_for(M, N, Kd), colsum_a=gb)   # dW and db in one pass
+        # dW and db in one pass, on the side stream (runtime.WgradStream): nothing in backward consumes them
+        WgradStream.run(lambda: K.gemm(g2, x2, trans_a=True, trans_b=True, out=gw, accumulate=True, split_k=split_k_for(M, N, Kd), colsum_a=gb), g2, x2)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.gemm(g2, w, trans_b=True).view(xshape)
@@ -359,8 +361,8 @@ class FusedCrossKVFn(Function):
             elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
                 dst.copy_(g)
         g2 = buf.view(Rm, L * 2 * d)
-        K.gemm_row_groups(g2, mem2, pack["gw"], L * 2 * d, d, Rm, trans_a=True, trans_b=True, accumulate=True, split_k=split_k_for(Rm, L * 2 * d, d),
-                          colsum_a=pack["gb"], group=(2 * d, 3 * d, d, 3))
+        WgradStream.run(lambda: K.gemm_row_groups(g2, mem2, pack["gw"], L * 2 * d, d, Rm, trans_a=True, trans_b=True, accumulate=True,
+                                                  split_k=split_k_for(Rm, L * 2 * d, d), colsum_a=pack["gb"], group=(2 * d, 3 * d, d, 3)), g2, mem2)
         dmem = None
         if ctx.needs_input_grad[0]:
             dmem = torch.empty((Rm, d), dtype=mem2.dtype, device=mem2.device)

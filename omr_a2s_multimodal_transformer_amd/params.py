@@ -103,6 +103,8 @@ class FlatParams:
             K.cast(self.master, torch.bfloat16, out=self.lowp)
 
     def zero_grad(self) -> None:
+        from .runtime import WgradStream
+        WgradStream.join()
         self.grad.zero_()
 
     def slice_of(self, names: Iterable[str]) -> Tuple[int, int]:
@@ -132,6 +134,8 @@ class FusedAdam:
         g = self.param_groups[0]
         self.step_count += 1
         f = self.flat
+        from .runtime import WgradStream
+        WgradStream.join()
         K.adam_step(f.master, f.grad, f.exp_avg, f.exp_avg_sq, self.step_count, g["lr"], g["betas"], g["eps"], grad_scale, p_lowp=f.lowp)
 
     def state_dict(self):

@@ -24,6 +24,50 @@ def next_seed() -> int:
     return _seed_stream.getrandbits(63)
 
 
+class WgradStream:
+    """Side HIP stream for the decoder's weight-gradient GEMMs.  dW = dY^T X of a linear has no consumer inside backward
+    and, at d_model = 256, fills a quarter of the CUs for a few tens of microseconds: issued on a second stream it runs
+    under the data-gradient kernels of the main stream instead of between them.  Ordering: the side stream waits for the main
+    stream's position at every hand-off (its inputs were produced there); the main stream waits for the side stream once,
+    when the backward pass ends (autograd engine callback), and before anything else that touches the flat gradient buffer
+    (all-reduce buckets, zero_grad, Adam -- they call join()).  Tensors read on the side stream are recorded on it so the
+    caching allocator does not hand their memory out early."""
+
+    enabled = True
+    _side = {}
+    _pending = {}          # device index -> the stream that has to wait
+
+    @classmethod
+    def run(cls, fn, *tensors) -> None:
+        t0 = tensors[0]
+        if not (cls.enabled and t0.is_cuda):
+            fn()
+            return
+        dev = t0.device.index
+        side = cls._side.get(dev)
+        if side is None:
+            side = cls._side[dev] = torch.cuda.Stream(device=t0.device)
+        main = torch.cuda.current_stream(t0.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            fn()
+        for t in tensors:
+            t.record_stream(side)
+        first = not cls._pending
+        cls._pending[dev] = main
+        if first:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(cls.join)
+            except RuntimeError:      # not inside a backward pass (direct call from a test): order it right away
+                cls.join()
+
+    @classmethod
+    def join(cls) -> None:
+        for dev, main in list(cls._pending.items()):
+            main.wait_stream(cls._side[dev])
+        cls._pending.clear()
+
+
 class FlatModuleMixin:
     """Adds flat-buffer parameter storage (params.py) to a top-level nn.Module."""
 

@@ -1,7 +1,8 @@
 """Per-kernel time summary of a rocprofv3 --kernel-trace --stats --output-format csv run: python tools/prof_summary.py <dir> <steps+warmup> <rows>."""
 import csv, glob, sys
 d = sys.argv[1]; steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-f = glob.glob(d + '/*/*_kernel_stats.csv')[0]
+import os
+f = max(glob.glob(d + '/*/*_kernel_stats.csv'), key=os.path.getmtime)      # newest run in the directory
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print("total ms/step", round(tot/1e6/steps, 2))
