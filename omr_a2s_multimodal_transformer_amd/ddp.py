@@ -72,20 +72,24 @@ class GradReducer:
 
 
 class GradBoundary(Function):
-    """Identity in forward; in backward, signals that every gradient produced AFTER this point of the forward
-    (i.e. earlier in backward) is final, and launches the given buckets' all-reduce."""
+    """Identity on one or more tensors in forward; in backward -- which autograd runs once the gradients of ALL of them are
+    known -- signals that every gradient produced AFTER this point of the forward (i.e. earlier in backward) is final, and
+    launches the given buckets' all-reduce.  Several tensors: the two encoder memories of MultimodalTransformer, behind
+    which the mixer and the decoder lie; a memory the step did not use simply has no gradient."""
 
     @staticmethod
-    def forward(ctx, x, reducer, bucket_ids):
+    def forward(ctx, reducer, bucket_ids, *xs):
         ctx.reducer, ctx.bucket_ids = reducer, bucket_ids
-        return x.view_as(x)
+        ctx.set_materialize_grads(False)
+        outs = tuple(x.view_as(x) for x in xs)
+        return outs[0] if len(outs) == 1 else outs
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         if ctx.reducer is not None:
             for i in ctx.bucket_ids:
                 ctx.reducer.reduce_bucket(i)
-        return g, None, None
+        return (None, None) + tuple(gs)
 
 
 def shard_indices(n_samples: int, rank: int, world: int, epoch: int = 0, shuffle: bool = True, seed: int = 0) -> List[int]:

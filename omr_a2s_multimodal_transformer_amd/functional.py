@@ -113,7 +113,7 @@ class DwConv3x3Fn(Function):
         (x,) = ctx.saved_tensors
         weight, bias, stats = ctx.weight, ctx.bias, ctx.stats
         g = gy.contiguous()
-        WgradStream.run(lambda: K.dwconv3x3_wgrad(x, g, weight.omr_grad, bias.omr_grad, in_stats=stats), x, g, *(stats or ()))
+        WgradStream.run("depthwise", lambda: K.dwconv3x3_wgrad(x, g, weight.omr_grad, bias.omr_grad, in_stats=stats), x, g, *(stats or ()))
         dx = None
         if ctx.needs_input_grad[0]:
             w = wt(weight, x.dtype)
@@ -173,7 +173,7 @@ class LinearFn(Function):
             g2 = K.relu_bwd(g2.contiguous(), y2, own_scale)     # y2 is the stored (dropped) output: ReLU + dropout backward in one mask
         M = g2.shape[0]
         # dW and db in one pass, on the side stream (runtime.WgradStream): nothing in backward consumes them
-        WgradStream.run(lambda: K.gemm(g2, x2, trans_a=True, trans_b=True, out=gw, accumulate=True, split_k=split_k_for(M, N, Kd), colsum_a=gb), g2, x2)
+        WgradStream.run("linear", lambda: K.gemm(g2, x2, trans_a=True, trans_b=True, out=gw, accumulate=True, split_k=split_k_for(M, N, Kd), colsum_a=gb), g2, x2)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.gemm(g2, w, trans_b=True).view(xshape)
@@ -361,7 +361,7 @@ class FusedCrossKVFn(Function):
             elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
                 dst.copy_(g)
         g2 = buf.view(Rm, L * 2 * d)
-        WgradStream.run(lambda: K.gemm_row_groups(g2, mem2, pack["gw"], L * 2 * d, d, Rm, trans_a=True, trans_b=True, accumulate=True,
+        WgradStream.run("cross_kv", lambda: K.gemm_row_groups(g2, mem2, pack["gw"], L * 2 * d, d, Rm, trans_a=True, trans_b=True, accumulate=True,
                                                   split_k=split_k_for(Rm, L * 2 * d, d), colsum_a=pack["gb"], group=(2 * d, 3 * d, d, 3)), g2, mem2)
         dmem = None
         if ctx.needs_input_grad[0]:

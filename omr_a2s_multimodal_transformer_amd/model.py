@@ -124,12 +124,13 @@ class _Base(FlatModuleMixin, LightningModule):
         self._reducer = GradReducer(flat, process_group, buckets)
         return self._reducer
 
-    def _boundary(self, mem: torch.Tensor) -> torch.Tensor:
-        """Memory hand-off encoder -> decoder: when backward gets here every decoder-side gradient is final."""
+    def _boundary(self, *mems: torch.Tensor):
+        """Memory hand-off encoder(s) -> [mixer ->] decoder: when backward gets here every gradient of the decoder-side bucket
+        is final."""
         if self._reducer is None or not torch.is_grad_enabled():
-            return mem
+            return mems[0] if len(mems) == 1 else mems
         from .ddp import GradBoundary
-        return GradBoundary.apply(mem, self._reducer, (1,))
+        return GradBoundary.apply(self._reducer, (1,), *mems)
 
     def configure_optimizers(self):
         """torch.optim.Adam(lr=1e-4, amsgrad=False) over all parameters (model.py:134-139,475-483) as ONE fused kernel."""
@@ -405,6 +406,7 @@ class MultimodalTransformer(_Base):
         """model.py:485-522: BOTH encoders always run; one memory may then be returned alone."""
         xi = self._encode(self.image_encoder, self.image_pos_2d, xi)
         xa = self._encode(self.audio_encoder, self.audio_pos_2d, xa)
+        xi, xa = self._boundary(xi, xa)
         if apply_teacher_forcing_modality:
             modality = self.apply_teacher_forcing_modality()
             if modality == "image":

@@ -34,13 +34,14 @@ class WgradStream:
     caching allocator does not hand their memory out early."""
 
     enabled = True
+    kinds = {"linear", "depthwise", "cross_kv"}     # which weight gradients take the side stream (tests narrow this)
     _side = {}
     _pending = {}          # device index -> the stream that has to wait
 
     @classmethod
-    def run(cls, fn, *tensors) -> None:
+    def run(cls, kind, fn, *tensors) -> None:
         t0 = tensors[0]
-        if not (cls.enabled and t0.is_cuda):
+        if not (cls.enabled and kind in cls.kinds and t0.is_cuda):
             fn()
             return
         dev = t0.device.index

@@ -48,7 +48,7 @@ def _worker(rank, world, port, q):
     # 2) boundary fired from backward reduces ONLY its bucket; finish() does the rest exactly once
     flat.grad.fill_(float(rank + 1))
     x = torch.ones(2, requires_grad=True)
-    y = GradBoundary.apply(x * 2.0, red, (1,))
+    y = GradBoundary.apply(red, (1,), x * 2.0)
     y.sum().backward()
     for h in red.handles:
         h.wait()

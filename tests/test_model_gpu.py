@@ -298,6 +298,7 @@ def test_decoder_bucket_is_final_when_backward_crosses_the_memory_boundary():
     memory hand-off.  Every decoder-side gradient -- including the embedding's and the fused cross-attention K|V
     projection's, whose nodes are not ancestors of the memory gradient -- must already be final at that moment."""
     from omr_a2s_multimodal_transformer_amd.ddp import GradReducer
+    from omr_a2s_multimodal_transformer_amd.runtime import WgradStream
 
     class Probe(GradReducer):
         def __init__(self, *a, **k):
@@ -306,6 +307,7 @@ def test_decoder_bucket_is_final_when_backward_crosses_the_memory_boundary():
 
         def reduce_bucket(self, i):
             if i not in self.snap:
+                WgradStream.join()              # what GradReducer.reduce_bucket does before it records its event
                 b, e = self.buckets[i]
                 self.snap[i] = self.flat.grad[b:e].clone()
 
@@ -324,6 +326,85 @@ def test_decoder_bucket_is_final_when_backward_crosses_the_memory_boundary():
     final = m._flat.grad[b:e]
     assert final.abs().max() > 0
     assert torch.equal(probe.snap[1], final), "a decoder gradient changed after the bucket was handed to the all-reduce"
+
+
+@pytest.mark.parametrize("mt,modality", [("concat", "both"), ("attn_both", "both"), ("attn_img", "both"), ("attn_both", "image")])
+def test_multimodal_decoder_bucket_is_final_at_the_two_memory_boundary(mt, modality):
+    """MultimodalTransformer under DDP: the decoder-side bucket (decoder + mixer attention) is handed to the all-reduce
+    when backward has the gradients of BOTH encoder memories (one GradBoundary node over the pair) -- also in the steps
+    that drop a modality, where one memory has no gradient at all."""
+    from omr_a2s_multimodal_transformer_amd.ddp import GradReducer
+    from omr_a2s_multimodal_transformer_amd.model import MultimodalTransformer
+    from omr_a2s_multimodal_transformer_amd.runtime import WgradStream
+
+    class Probe(GradReducer):
+        snap = None
+
+        def reduce_bucket(self, i):
+            if i == 1 and self.snap is None:
+                WgradStream.join()
+                b, e = self.buckets[1]
+                self.snap = self.flat.grad[b:e].clone()
+
+    V = 40
+    w2i, i2w = syn.make_vocab(V)
+    m = MultimodalTransformer(32, 48, 35, 40, 12, w2i, i2w, mixer_type=mt, config=ModelConfig(num_layers=2, **NO_DROP))
+    load_seeded(m, syn.multimodal_shapes(V, mt, layers=2), 52)
+    m.flatten_parameters()
+    m.train()
+    real = m.attach_reducer()
+    probe = Probe(m._flat, None, real.buckets)
+    m._reducer = probe
+    xi, xli, y_in, y_out = syn.synthetic_unimodal_batch(3, 32, 48, 9, V, w2i["<sos>"], w2i["<eos>"], seed=6)
+    xa, xla, _, _ = syn.synthetic_unimodal_batch(3, 35, 40, 9, V, w2i["<sos>"], w2i["<eos>"], seed=7, pad_value=0.0)
+    m.apply_teacher_forcing_modality = lambda: modality
+    m.zero_grad()
+    logits = m(xi.to(DEV), xli.to(DEV), xa.to(DEV), xla.to(DEV), y_in.to(DEV), apply_teacher_forcing_modality=True)
+    m.compute_loss(logits, y_out.to(DEV)).backward()
+    assert probe.snap is not None, "backward never crossed the memory boundary"
+    b, e = probe.buckets[1]
+    final = m._flat.grad[b:e]
+    assert final.abs().max() > 0
+    assert torch.equal(probe.snap, final), "a decoder-side gradient changed after the bucket was handed to the all-reduce"
+    eb, ee = probe.buckets[0]
+    assert m._flat.grad[eb:ee].abs().max() > 0          # the encoders did get their gradients afterwards
+
+
+def test_side_stream_weight_gradients_are_complete_and_equal_to_in_order_ones():
+    """runtime.WgradStream: weight-gradient GEMMs / depthwise weight gradients issued on the side stream must all have
+    landed in the flat gradient buffer when backward returns (engine callback joins the streams), and must equal the
+    gradients of the same pass with everything on one stream (up to the order of the fp32 atomics)."""
+    from omr_a2s_multimodal_transformer_amd.runtime import WgradStream
+    V = 60
+    m, w2i = make_transformer(V, ModelConfig(num_layers=2, **NO_DROP), 43, hw=(64, 128), max_seq=24)
+    m.train()
+    m.teacher_forcing_prob = 0.0
+    x, xl, y_in, y_out = (t.to(DEV) for t in syn.synthetic_unimodal_batch(3, 64, 128, 20, V, w2i["<sos>"], w2i["<eos>"], seed=6))
+    grads = {}
+    try:
+        for mode in (False, False, True, True):
+            WgradStream.enabled = mode
+            m.zero_grad()
+            m.compute_loss(m(x, xl, y_in), y_out).backward()
+            assert not WgradStream._pending, "backward returned with un-joined side-stream work"
+            grads.setdefault(mode, []).append(m._flat.grad.clone())
+    finally:
+        WgradStream.enabled = True
+    ref = grads[False][0]
+    assert ref.abs().max() > 0
+    # Decoder-side gradients (every side-stream GEMM of the decoder) must agree to fp32-atomics noise.  Encoder gradients are
+    # compared at 5 %: independent of the stream layout, two runs of the SAME configuration differ there by up to ~1 % in a
+    # few discrete patterns, because the constant padding of the synthetic images normalises to +-1e-8 under InstanceNorm
+    # (fp64 atomics, order varies) and the ReLU mask of such an element flips -- the loss does not move.  A lost or torn
+    # weight gradient would be an O(1) error in its own slice, which both bounds catch.
+    for g in grads[True] + grads[False][1:]:
+        for n, (o, c) in m._flat.offsets.items():
+            r = ref[o:o + c]
+            if r.abs().max() == 0:
+                continue
+            assert g[o:o + c].abs().max() > 0, f"{n}: gradient missing"
+            rel = ((g[o:o + c] - r).norm() / r.norm()).item()
+            assert rel < (1e-5 if n.startswith("decoder.") else 5e-2), (n, rel)
 
 
 @pytest.mark.parametrize("dtype,win", [("fp32", -1), ("fp32", 4), ("bf16", -1)])
