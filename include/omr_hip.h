@@ -52,6 +52,21 @@ int omr_argmax(const float* x, int rows, int n, long ld, long* idx_out, float* v
  * (re | im); this turns it into the reference's normalised log-spectrogram out [bins][frames] =
  * amplitude_to_db(|S|, ref=max, top_db=80) / 80 + 1.  spec is overwritten (magnitudes); max_ws: 4 bytes of device scratch. */
 int omr_log_stft_post(float* spec, long frames, int bins, unsigned* max_ws, float* out, void* stream);
+/* score-image front end (preprocessing.py:44-52: PIL convert("L") -> Image.resize (Pillow's default BICUBIC, antialiased,
+ * 8-bit fixed point) -> ToTensor).  Bit-exact with Pillow.
+ *   omr_resample_ksize / omr_resample_coeffs: HOST functions (no GPU work): taps per output pixel, and the tables
+ *     bounds [out_size][2] = (first input index, count), coefs [out_size][ksize] (22 fractional bits); coeffs returns ksize.
+ *   omr_image_gray_hpass: interleaved 8-bit pixels (channels 1 = L, 3 = RGB, 4 = RGBA; row_stride in bytes) -> luma ->
+ *     horizontal pass -> dst [h][out_w] uint8.  bounds = coefs = NULL (out_w == w): conversion only.
+ *   omr_image_vpass_to_float: vertical pass over src [h][w] uint8 -> value / 255 as out_dtype (OMR_F32 / OMR_BF16) into
+ *     dst rows of dst_row_stride elements (a sample's slot inside the padded batch tensor, preprocessing.py:55-75).
+ *     bounds = coefs = NULL (out_h == h): conversion only. */
+int omr_resample_ksize(int in_size, int out_size);
+int omr_resample_coeffs(int in_size, int out_size, int* bounds, int* coefs);
+int omr_image_gray_hpass(const unsigned char* src, int h, int w, int channels, long row_stride, const int* bounds, const int* coefs,
+                         int ksize, int out_w, unsigned char* dst, void* stream);
+int omr_image_vpass_to_float(const unsigned char* src, int h, int w, const int* bounds, const int* coefs, int ksize, int out_h,
+                             int out_dtype, void* dst, long dst_row_stride, void* stream);
 /* beam-search expansion (BASELINE config C5; an extension: the reference decodes greedily): per row the k largest
  * log_softmax values and their token ids, same tie rule as omr_argmax, idx_out / val_out [rows][k] */
 int omr_topk_logprob(const float* x, int rows, int n, long ld, int k, long* idx_out, float* val_out, void* stream);

@@ -17,6 +17,8 @@ root).  All dropout layers are identity here (eval-mode / p=0 parity, SURVEY.md 
 from __future__ import annotations
 
 import math
+
+import numpy as np
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -427,3 +429,83 @@ def log_stft(y, n_fft: int = 2048, hop: int = 512, sr: int = 22050, fmax: float 
     db = 20.0 * np.log10(np.maximum(amin, mag)) - 20.0 * np.log10(max(amin, mag.max()))
     db = np.maximum(db, db.max() - 80.0)
     return (db / 80.0 + 1.0).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# score-image front end (src/data/preprocessing.py:44-52)
+# --------------------------------------------------------------------------------------
+# PIL convert("L") -> Image.resize((int(H * w / h), H)) -> ToTensor.  The arithmetic lives in Pillow (third-party; the
+# reference pins no version, the build container has 12.2.0): restated here from Pillow's documented 8-bit resampler and
+# PINNED against Pillow itself -- tests/golden/f11_image.npz holds Pillow's outputs (tests/golden/gen_image_golden.py),
+# and tests/test_oracle_golden.py also compares with the importable Pillow directly.  Integer work: bit-exact.
+
+def pil_gray(rgb: np.ndarray) -> np.ndarray:
+    """uint8 [h, w] / [h, w, 3|4] -> uint8 [h, w]: L = (19595 R + 38470 G + 7471 B + 0x8000) >> 16 (alpha ignored)."""
+    a = np.asarray(rgb)
+    if a.ndim == 2 or a.shape[2] == 1:
+        return a.reshape(a.shape[0], a.shape[1]).copy()
+    r, g, b = (a[..., i].astype(np.uint32) for i in range(3))
+    return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def pil_bicubic_tables(in_size: int, out_size: int):
+    """Per output pixel: first contributing input pixel, tap count, and the taps in 22-bit fixed point (Keys cubic a = -0.5,
+    support 2 stretched by max(1, in/out), normalised in double precision)."""
+    scale = in_size / out_size
+    fs = max(scale, 1.0)
+    support = 2.0 * fs
+    ksize = int(np.ceil(support)) * 2 + 1
+
+    def cubic(x: float) -> float:
+        a = -0.5
+        x = abs(x)
+        if x < 1.0:
+            return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+        if x < 2.0:
+            return (((x - 5) * x + 8) * x - 4) * a
+        return 0.0
+
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    coefs = np.zeros((out_size, ksize), dtype=np.int32)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [cubic((x + xmin - center + 0.5) * (1.0 / fs)) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        if ww != 0.0:
+            w = [v / ww for v in w]
+        bounds[xx] = (xmin, xmax)
+        for x, v in enumerate(w):
+            coefs[xx, x] = int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22))
+    return bounds, coefs
+
+
+def _pil_pass(img: np.ndarray, bounds: np.ndarray, coefs: np.ndarray) -> np.ndarray:
+    """One horizontal pass: uint8 [h, w] -> uint8 [h, out_w]."""
+    out = np.empty((img.shape[0], bounds.shape[0]), dtype=np.uint8)
+    src = img.astype(np.int64)
+    for xx, (xmin, n) in enumerate(bounds):
+        ss = (src[:, xmin:xmin + n] * coefs[xx, :n].astype(np.int64)).sum(axis=1) + (1 << 21)
+        out[:, xx] = np.clip(ss >> 22, 0, 255)
+    return out
+
+
+def pil_resize_L(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """Image.resize((out_w, out_h)) of a mode-"L" image: horizontal pass, then vertical pass, each only if that size changes."""
+    h, w = img.shape
+    if out_w != w:
+        img = _pil_pass(img, *pil_bicubic_tables(w, out_w))
+    if out_h != h:
+        img = _pil_pass(np.ascontiguousarray(img.T), *pil_bicubic_tables(h, out_h)).T
+    return np.ascontiguousarray(img)
+
+
+def preprocess_image(pixels: np.ndarray, img_height=None) -> np.ndarray:
+    """preprocessing.py:44-52 on uint8 pixels -> float32 [1, H, W] in [0, 1]."""
+    g = pil_gray(pixels)
+    if img_height is not None:
+        g = pil_resize_L(g, img_height, int(img_height * g.shape[1] / g.shape[0]))
+    return (g.astype(np.float32) / np.float32(255.0))[None]
