@@ -327,40 +327,57 @@ __global__ __launch_bounds__(192) void conv1_wgrad_kernel(const T* __restrict__ 
     for (int n = 0; n < COUT; ++n) { acc[0][n] = acc[1][n] = acc[2][n] = 0.f; accb[n] = 0.f; }
     if (j < Wd) {
         const int rows = B * H;
+        // Loads are unconditional (row clamped by the caller, out-of-image tap rows read a valid row and are zeroed by a
+        // factor): a load behind a branch makes the compiler's vmcnt bookkeeping pessimistic and the ring collapses into
+        // one round trip per row.
         auto load = [&](int row, float (&xv)[3], F (&gv)[NV]) {
             const int i = row % H;
             const int yy = i + kh - 1;
-            xv[0] = xv[1] = xv[2] = 0.f;
-            if (yy >= 0 && yy < H) {
-                const T* xr = x + (long)(row + kh - 1) * Wd;
-                xv[0] = j > 0 ? to_f32(xr[j - 1]) : 0.f;
-                xv[1] = to_f32(xr[j]);
-                xv[2] = j + 1 < Wd ? to_f32(xr[j + 1]) : 0.f;
-            }
+            const bool ok = yy >= 0 && yy < H;
+            const float m = ok ? 1.f : 0.f;
+            const T* xr = x + (long)(ok ? row + kh - 1 : row) * Wd;
+            const int jl = j > 0 ? j - 1 : j, jr = j + 1 < Wd ? j + 1 : j;
+            const T xl = xr[jl], xc = xr[j], xrr = xr[jr];          // three unconditional loads; the image border is a factor
+            xv[0] = to_f32(xl) * (j > 0 ? m : 0.f);
+            xv[1] = to_f32(xc) * m;
+            xv[2] = to_f32(xrr) * (j + 1 < Wd ? m : 0.f);
             const F* gp = reinterpret_cast<const F*>(dy + ((long)row * Wd + j) * COUT);
 #pragma unroll
             for (int v = 0; v < NV; ++v) gv[v] = gp[v];
         };
-        float xv[3], xn[3] = {0.f, 0.f, 0.f};
-        F gv[NV], gn[NV];
-        if ((int)blockIdx.y < rows) load(blockIdx.y, xv, gv);
-        for (int row = blockIdx.y; row < rows; row += gridDim.y) {
-            const int next = row + gridDim.y;
-            if (next < rows) load(next, xn, gn);                 // the next row's loads fly behind this row's FMAs
+        // ring of PD rows in flight per lane (one row = 32 bytes of dy per lane: a single row ahead leaves the kernel waiting
+        // on HBM latency at 1.4 TB/s)
+        constexpr int PD = 4;
+        float xq[PD][3];
+        F gq[PD][NV];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
+        for (int d = 0; d < PD; ++d) {
+            xq[d][0] = xq[d][1] = xq[d][2] = 0.f;
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const float g = to_f32(gv[v][e]);
-                    const int n = v * VEC + e;
-                    acc[0][n] += g * xv[0]; acc[1][n] += g * xv[1]; acc[2][n] += g * xv[2];
-                    if (kh == 1) accb[n] += g;
+            for (int v = 0; v < NV; ++v) gq[d][v] = frag_zero<T>();
+            load(min((int)(blockIdx.y + d * gridDim.y), rows - 1), xq[d], gq[d]);
+        }
+        for (int row0 = blockIdx.y; row0 < rows; row0 += PD * gridDim.y) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+                const int row = row0 + d * gridDim.y;
+                if (row >= rows) break;
+                float xv[3] = {xq[d][0], xq[d][1], xq[d][2]};
+                F gv[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) gv[v] = gq[d][v];
+                load(min(row + PD * (int)gridDim.y, rows - 1), xq[d], gq[d]);       // refill this slot: PD rows stay in flight behind the FMAs
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float g = to_f32(gv[v][e]);
+                        const int n = v * VEC + e;
+                        acc[0][n] += g * xv[0]; acc[1][n] += g * xv[1]; acc[2][n] += g * xv[2];
+                        if (kh == 1) accb[n] += g;
+                    }
                 }
             }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) xv[c] = xn[c];
-#pragma unroll
-            for (int v = 0; v < NV; ++v) gv[v] = gn[v];
         }
     }
     // columns beyond the image hold zeros: every lane takes part in the wave reductions

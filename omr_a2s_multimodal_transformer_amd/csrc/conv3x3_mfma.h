@@ -7,6 +7,7 @@
 
 namespace omr_conv {
 
+constexpr int NORM_MAX = 128;   // most input channels a normalise-on-load conv may have (LDS copy of the statistics)
 constexpr int TW = 32;  // output tile width = one MFMA M-block (32 pixels of one output row)
 
 // Walk tile pixels pix = pix0 + k*DP (k = 0, 1, ...) keeping an incremental (row, col) inside a tile of width IW, in
@@ -106,6 +107,14 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? 3 : 2) void conv3x3_mfm
     __shared__ __attribute__((aligned(16))) float sbias[NT];     // bias of this block's couts (read back as float4 runs)
     for (int i = tid; i < NT; i += 256) sbias[i] = (a.bias && n0 + i < a.COUT) ? a.bias[n0 + i] : 0.f;
 
+    // fused InstanceNorm-apply on load: the (mean, rstd) rows of this block's image, staged once (a block sees one image)
+    __shared__ __attribute__((aligned(16))) float snorm[2 * NORM_MAX];
+    if (a.mean)
+        for (int i = tid; i < a.CIN; i += 256) {
+            snorm[i] = a.mean[(long)blockIdx.z * a.CIN + i];
+            snorm[NORM_MAX + i] = a.rstd[(long)blockIdx.z * a.CIN + i];
+        }
+
     if (single) stage_weights(0);
 
     // fused reductions: this thread always stores the same VEC-channel chunk, so it keeps fp32 partials in registers and the
@@ -181,13 +190,16 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? 3 : 2) void conv3x3_mfm
 #pragma unroll
         for (int r = 0; r < XR; ++r) {
             const int pix = tid + r * 256;
-            if (a.mean && ((xok >> r) & 1)) {
+            if (a.mean && ((xok >> r) & 1)) {      // statistics of this block's image from LDS (broadcast 16-byte reads)
 #pragma unroll
                 for (int k = 0; k < CPP; ++k)
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const int ch = b * a.CIN + c0 + k * VEC + e;
-                        xv[r][k][e] = from_f32<T>((to_f32(xv[r][k][e]) - a.mean[ch]) * a.rstd[ch]);
+                    for (int q4 = 0; q4 < VEC / 4; ++q4) {
+                        const f32x4 mu = *reinterpret_cast<const f32x4*>(&snorm[c0 + k * VEC + 4 * q4]);
+                        const f32x4 rs = *reinterpret_cast<const f32x4*>(&snorm[NORM_MAX + c0 + k * VEC + 4 * q4]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            xv[r][k][4 * q4 + e] = from_f32<T>((to_f32(xv[r][k][4 * q4 + e]) - mu[e]) * rs[e]);
                     }
             }
             if (pix < NPIX)
@@ -360,6 +372,7 @@ template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, b
     if (!SINGLE && (size_t)TH * TW * OP * sizeof(T) > shm) shm = (size_t)TH * TW * OP * sizeof(T);
     if (shm > 160 * 1024) return OMR_ERR_UNSUPPORTED;
     if (a.COUT % Frag<T>::N) return OMR_ERR_UNSUPPORTED;
+    if (a.mean && a.CIN > NORM_MAX) return OMR_ERR_UNSUPPORTED;
     auto kern = conv3x3_mfma_kernel<T, NT, RPW, CK, SH, SW, DH, DW, SINGLE, EPI>;
     if (shm > 48 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return OMR_ERR_LAUNCH;

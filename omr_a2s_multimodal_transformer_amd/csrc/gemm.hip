@@ -144,7 +144,10 @@ __device__ __forceinline__ typename Frag<T>::type load_frag(const T* lds, int ro
     }
 }
 
-template <typename T, typename TC, bool TA, bool TB>
+// FULLK (forward-type GEMMs with K <= 4 BK, i.e. d_model = 256 in bf16): all k-slabs of both operands are requested up front
+// (one global round trip instead of four dependent ones -- these GEMMs are latency chains, not throughput problems), at
+// the price of 96 more staging registers.
+template <typename T, typename TC, bool TA, bool TB, bool FULLK>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     typedef GemmCfg<T> Cfg;
     typedef typename Frag<T>::type F;
@@ -177,19 +180,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int e = 0; e < Cfg::VEC; ++e) cs[e] = 0.f;
     const bool do_cs = TA && g.colsum_a != nullptr && tile.n == 0;
-    sa.load(A, g.lda, m0, g.M, kbeg, kend, tid);
-    sb.load(B + grp_delta(g, 2, kbeg) * g.ldb, g.ldb, n0, g.N, kbeg, kend, tid);
-    if (do_cs) sa.add_colsum(cs);
-    sa.store(As, tid);
-    sb.store(Bs, tid);
-    __syncthreads();
-
-    for (int k0 = kbeg; k0 < kend; k0 += Cfg::BK) {
-        const bool more = (k0 + Cfg::BK) < kend;
-        if (more) {
-            sa.load(A, g.lda, m0, g.M, k0 + Cfg::BK, kend, tid);
-            sb.load(B + grp_delta(g, 2, k0 + Cfg::BK) * g.ldb, g.ldb, n0, g.N, k0 + Cfg::BK, kend, tid);
-        }
+    auto mma_slab = [&]() {
 #pragma unroll
         for (int ks = 0; ks < Cfg::BK; ks += KStep<T>::value) {
             F a[2], b[2];
@@ -205,6 +196,42 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                     else mma32(acc[i][j], a[i], b[j]);                     // D[m][n]: lane = column n
                 }
         }
+    };
+    if constexpr (FULLK) {
+        Stager<T, TA> fa[4];
+        Stager<T, TB> fb[4];
+        const int nk = (kend - kbeg + Cfg::BK - 1) / Cfg::BK;        // host guarantees nk <= 4, one split
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+            if (sl < nk) {
+                fa[sl].load(A, g.lda, m0, g.M, kbeg + sl * Cfg::BK, kend, tid);
+                fb[sl].load(B + grp_delta(g, 2, kbeg + sl * Cfg::BK) * g.ldb, g.ldb, n0, g.N, kbeg + sl * Cfg::BK, kend, tid);
+            }
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+            if (sl < nk) {
+                if (sl) __syncthreads();
+                fa[sl].store(As, tid);
+                fb[sl].store(Bs, tid);
+                __syncthreads();
+                mma_slab();
+            }
+        __syncthreads();
+    } else {
+    sa.load(A, g.lda, m0, g.M, kbeg, kend, tid);
+    sb.load(B + grp_delta(g, 2, kbeg) * g.ldb, g.ldb, n0, g.N, kbeg, kend, tid);
+    if (do_cs) sa.add_colsum(cs);
+    sa.store(As, tid);
+    sb.store(Bs, tid);
+    __syncthreads();
+
+    for (int k0 = kbeg; k0 < kend; k0 += Cfg::BK) {
+        const bool more = (k0 + Cfg::BK) < kend;
+        if (more) {
+            sa.load(A, g.lda, m0, g.M, k0 + Cfg::BK, kend, tid);
+            sb.load(B + grp_delta(g, 2, k0 + Cfg::BK) * g.ldb, g.ldb, n0, g.N, k0 + Cfg::BK, kend, tid);
+        }
+        mma_slab();
         __syncthreads();
         if (more) {
             if (do_cs) sa.add_colsum(cs);   // here the prefetched registers are needed anyway (no extra wait)
@@ -212,6 +239,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             sb.store(Bs, tid);
             __syncthreads();
         }
+    }
     }
 
     if (do_cs) {   // combine the 256 per-thread partials in LDS (operand tiles are dead), then ONE global atomic per row per block
@@ -314,14 +342,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
 template <typename T, typename TC> int launch(GemmArgs g, int ta, int tb, int splits, hipStream_t s) {
     g.nt = cdiv(g.N, BN); g.mt = cdiv(g.M, BM);
+    const bool fullk = !ta && splits == 1 && g.K <= 4 * GemmCfg<T>::BK;
     g.total = g.nt * g.mt * splits;
     g.chunk = splits > 1 ? g.nt * g.mt : g.nt;
     const int nchunks = g.total / g.chunk;
     dim3 grid((unsigned)(cdiv(nchunks, 8) * 8 * g.chunk)), block(256);
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, TC, false, false>), grid, block, 0, s, g);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, TC, false, true>), grid, block, 0, s, g);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, TC, true, false>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<T, TC, true, true>), grid, block, 0, s, g);
+    if (!ta && !tb && fullk) hipLaunchKernelGGL((gemm_kernel<T, TC, false, false, true>), grid, block, 0, s, g);
+    else if (!ta && tb && fullk) hipLaunchKernelGGL((gemm_kernel<T, TC, false, true, true>), grid, block, 0, s, g);
+    else if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, TC, false, false, false>), grid, block, 0, s, g);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, TC, false, true, false>), grid, block, 0, s, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, TC, true, false, false>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<T, TC, true, true, false>), grid, block, 0, s, g);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }

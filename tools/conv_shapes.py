@@ -11,6 +11,7 @@ from tools.gemm_shapes import timeit                         # noqa: E402
 
 B = 32
 LAYERS = [  # name, H, W, cin, cout, stride
+    ("cb0.c1", 256, 2048, 1, 16, (1, 1)),
     ("cb0.c2", 256, 2048, 16, 16, (1, 1)), ("cb0.c3", 256, 2048, 16, 16, (1, 1)),
     ("cb1.c1", 256, 2048, 16, 32, (1, 1)), ("cb1.c2", 256, 2048, 32, 32, (1, 1)), ("cb1.c3", 256, 2048, 32, 32, (2, 2)),
     ("cb2.c1", 128, 1024, 32, 64, (1, 1)), ("cb2.c2", 128, 1024, 64, 64, (1, 1)), ("cb2.c3", 128, 1024, 64, 64, (2, 2)),
@@ -30,17 +31,21 @@ def main():
         bias = torch.zeros(co, device=dev)
         Ho, Wo = K.conv_out_hw(H, W, st)
         dy = torch.randn(B, Ho, Wo, co, device=dev, dtype=dt)
-        wf = K.conv3x3_weight_flip(w)
+        wf = K.conv3x3_weight_flip(w) if ci > 1 else None
         dw = torch.zeros(co, 3, 3, ci, device=dev)
         db = torch.zeros(co, device=dev)
         mb = (x.numel() + dy.numel()) * 2 / 1e6
         t_f = timeit(lambda: K.conv3x3(x, w, bias, stride=st, relu=True), 10)
-        t_d = timeit(lambda: K.conv3x3(dy, wf, None, stride=(1, 1), dil=st, out_hw=(H, W), out_mask=x, mask_scale=1.0), 10)
+        t_d = timeit(lambda: K.conv3x3(dy, wf, None, stride=(1, 1), dil=st, out_hw=(H, W), out_mask=x, mask_scale=1.0), 10) if ci > 1 else 0.0   # the first layer has no data gradient
         t_w = timeit(lambda: K.conv3x3_wgrad(x, dy, dw, stride=st, db=db), 10)
+        t_n = 0.0
+        if name.endswith(".c3"):                      # conv3 of a block reads its input through the fused InstanceNorm-apply
+            st_in = K.instnorm_stats(x)
+            t_n = timeit(lambda: K.conv3x3(x, w, bias, stride=st, relu=True, in_stats=st_in), 10)
         ideal = mb / 4.0
         for i, t in enumerate((ideal, t_f, t_d, t_w)):
             tot[i] += t
-        print(f"{name:8s} {mb:6.0f} {ideal:14.0f} | {t_f:7.0f} {t_d:7.0f} {t_w:7.0f}", flush=True)
+        print(f"{name:8s} {mb:6.0f} {ideal:14.0f} | {t_f:7.0f} {t_d:7.0f} {t_w:7.0f}" + (f"   fwd with IN-apply {t_n:5.0f}" if t_n else ""), flush=True)
     print("totals (ms): ideal %.2f fwd %.2f dgrad %.2f wgrad %.2f" % tuple(t / 1e3 for t in tot))
 
 
