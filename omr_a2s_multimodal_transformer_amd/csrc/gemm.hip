@@ -166,6 +166,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const T* A = (const T*)g.A;
     const T* B = (const T*)g.B + grp_delta(g, 1, n0) * g.ldb;
 
+    // bias of the tile's 128 columns -> LDS (the bf16 epilogue reads it as float4 runs; 32 gathered global loads per lane otherwise)
+    __shared__ __attribute__((aligned(16))) float sbias[BN];
+    if constexpr (SWAP) {
+        if (tid < BN) {
+            const float* bp = g.bias ? g.bias + grp_delta(g, 1, n0) : nullptr;
+            sbias[tid] = (bp != nullptr && tile.split == 0 && n0 + tid < g.N) ? bp[n0 + tid] : 0.f;
+        }
+    }
+
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -264,11 +273,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         const int hsel = 4 * (lane >> 5);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            float bv[16];
+            float bv[16];          // bias of this lane's 16 columns: four 16-byte reads of the block's LDS copy (staged at kernel start)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col = n0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + hsel;
-                bv[r] = (biasp != nullptr && tile.split == 0 && col < g.N) ? biasp[col] : 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(&sbias[wn * 64 + j * 32 + 8 * q + hsel]);
+                bv[4 * q] = b4[0]; bv[4 * q + 1] = b4[1]; bv[4 * q + 2] = b4[2]; bv[4 * q + 3] = b4[3];
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
