@@ -60,7 +60,7 @@ struct ConvArgs {
 // EPI selects the fused-epilogue code that is compiled in (keeps the plain kernel's register footprint small):
 //   0 plain | 1 forward extras: MixDropout + InstanceNorm statistics of the output | 2 backward extras: InstanceNorm-backward sums
 template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, bool SINGLE, int EPI>
-__global__ __launch_bounds__(256, (SINGLE && NT == 32) ? 3 : 2) void conv3x3_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (SINGLE && NT == 32) ? (CK == 16 ? 4 : 3) : 2) void conv3x3_mfma_kernel(ConvArgs a) {
     typedef typename Frag<T>::type F;
     typedef __attribute__((ext_vector_type(4))) T T4;
     constexpr int VEC = Frag<T>::N;
