@@ -419,6 +419,12 @@ def test_attention_dropout_consistency():
     dq, dk, dv = torch.empty_like(qg), torch.empty_like(kg), torch.empty_like(vg)
     k.attn_bwd(qg, kg, vg, o, g, lse, dq, dk, dv, nhead, dropout_p=0.3, seed=5)
     torch.testing.assert_close(dv[0], pd[0].t() @ g[0], rtol=1e-3, atol=1e-4)
+    # dQ / dK of both backward kernels against autograd through softmax -> (recovered mask) -> 1/(1-p) -> @ V
+    qa, ka = qg.cpu().clone().requires_grad_(True), kg.cpu().clone().requires_grad_(True)
+    mask = kept.cpu().float() / 0.7
+    (((torch.softmax(qa @ ka.transpose(1, 2) / math.sqrt(d), dim=-1) * mask) @ vg.cpu()) * g.cpu()).sum().backward()
+    torch.testing.assert_close(dq.cpu(), qa.grad, rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(dk.cpu(), ka.grad, rtol=2e-3, atol=2e-4)
 
 
 # ------------------------------------------------------------------------------------------------ loss
