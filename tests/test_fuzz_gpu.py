@@ -16,8 +16,13 @@ from oracle import ref_cpu as R  # noqa: E402
 BF, F32 = torch.bfloat16, torch.float32
 
 
+import os
+
+_SEED_SHIFT = int(os.environ.get("OMR_FUZZ_SEED_SHIFT", "0"))      # OMR_FUZZ_SEED_SHIFT=k draws a different set of shapes
+
+
 def _cases(seed, n, gen):
-    rng = random.Random(seed)
+    rng = random.Random(seed + 1000003 * _SEED_SHIFT)
     return [gen(rng) for _ in range(n)]
 
 
