@@ -77,12 +77,13 @@ def preprocess_image_into(pixels: Tensor, img_height: Optional[int], out: Tensor
         raise ValueError(f"resized image would be {H}x{W}")
     assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= H and out.shape[1] >= W
     dev = pixels.device
+    dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
     bh = ch = bv = cv = None
     ksh = ksv = 0
     if W != w:
-        bh, ch, ksh = _tables(w, W, dev.index)
+        bh, ch, ksh = _tables(w, W, dev_index)
     if H != h:
-        bv, cv, ksv = _tables(h, H, dev.index)
+        bv, cv, ksv = _tables(h, H, dev_index)
     if W != w or c != 1:
         tmp = torch.empty((h, W), dtype=torch.uint8, device=dev)
         lib().call("omr_image_gray_hpass", ptr(pixels), h, w, c, pixels.stride(0), ptr(bh), ptr(ch), ksh, W, ptr(tmp), cur_stream())
