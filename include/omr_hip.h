@@ -67,6 +67,13 @@ int omr_image_gray_hpass(const unsigned char* src, int h, int w, int channels, l
                          int ksize, int out_w, unsigned char* dst, void* stream);
 int omr_image_vpass_to_float(const unsigned char* src, int h, int w, const int* bounds, const int* coefs, int ksize, int out_h,
                              int out_dtype, void* dst, long dst_row_stride, void* stream);
+/* late (prediction-level) fusion, src/multimodal/smith_waterman/test.py:136-150: Smith-Waterman local alignment of the
+ * image model's and the audio model's token sequences.  HOST function (no GPU work).  Restates swalign 0.3.x's
+ * LocalAlignment (package absent here: PARITY UNPINNED).  ref / query: token ids; ops receives one of 'm' 'i' 'd' per
+ * alignment column (capacity nr + nq), r_pos / q_pos the 0-based start of the aligned region in ref / query; returns the
+ * number of columns. */
+int omr_sw_align(const int* ref, int nr, const int* query, int nq, int match, int mismatch, int gap_penalty,
+                 int gap_extension_penalty, char* ops, int* r_pos, int* q_pos, int* score);
 /* beam-search expansion (BASELINE config C5; an extension: the reference decodes greedily): per row the k largest
  * log_softmax values and their token ids, same tie rule as omr_argmax, idx_out / val_out [rows][k] */
 int omr_topk_logprob(const float* x, int rows, int n, long ld, int k, long* idx_out, float* val_out, void* stream);

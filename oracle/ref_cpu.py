@@ -509,3 +509,66 @@ def preprocess_image(pixels: np.ndarray, img_height=None) -> np.ndarray:
     if img_height is not None:
         g = pil_resize_L(g, img_height, int(img_height * g.shape[1] / g.shape[0]))
     return (g.astype(np.float32) / np.float32(255.0))[None]
+
+
+# --------------------------------------------------------------------------------------
+# late fusion (src/multimodal/smith_waterman/test.py:136-150)
+# --------------------------------------------------------------------------------------
+
+def sw_align(ref, query, match: int = 2, mismatch: int = -1, gap_penalty: int = -1, gap_extension_penalty: int = -1):
+    """Smith-Waterman local alignment as swalign 0.3.x's LocalAlignment.align computes it (restated from the package's
+    published algorithm; the package is absent here: PARITY UNPINNED).  Plain Python, small inputs only.
+    -> (ops, r_pos, q_pos, score); ops over {'m', 'i', 'd'}."""
+    nq, nr = len(query), len(ref)
+    val = [[0] * (nr + 1) for _ in range(nq + 1)]
+    op = [[" "] * (nr + 1) for _ in range(nq + 1)]
+    run = [[0] * (nr + 1) for _ in range(nq + 1)]
+    for row in range(1, nq + 1):
+        op[row][0] = "i"
+    for col in range(1, nr + 1):
+        op[0][col] = "d"
+    best = (0, 0, 0)
+    for row in range(1, nq + 1):
+        for col in range(1, nr + 1):
+            mm = val[row - 1][col - 1] + (match if query[row - 1] == ref[col - 1] else mismatch)
+            ins_run = del_run = 0
+            if op[row - 1][col] == "i":
+                ins_run = run[row - 1][col]
+                ins = 0 if val[row - 1][col] == 0 else val[row - 1][col] + gap_extension_penalty
+            else:
+                ins = val[row - 1][col] + gap_penalty
+            if op[row][col - 1] == "d":
+                del_run = run[row][col - 1]
+                dele = 0 if val[row][col - 1] == 0 else val[row][col - 1] + gap_extension_penalty
+            else:
+                dele = val[row][col - 1] + gap_penalty
+            cell = max(mm, dele, ins, 0)
+            if del_run and cell == dele:
+                o, rl = "d", del_run + 1
+            elif ins_run and cell == ins:
+                o, rl = "i", ins_run + 1
+            elif cell == mm:
+                o, rl = "m", 0
+            elif cell == dele:
+                o, rl = "d", 1
+            elif cell == ins:
+                o, rl = "i", 1
+            else:
+                o, rl, cell = "x", 0, 0
+            val[row][col], op[row][col], run[row][col] = cell, o, rl
+            if cell >= best[0]:
+                best = (cell, row, col)
+    score, row, col = best
+    ops = []
+    while val[row][col] > 0:
+        o = op[row][col]
+        ops.append(o)
+        if o == "m":
+            row, col = row - 1, col - 1
+        elif o == "i":
+            row -= 1
+        elif o == "d":
+            col -= 1
+        else:
+            break
+    return "".join(reversed(ops)), col, row, score
