@@ -8,7 +8,8 @@
  * all buffers (device pointers); `stream` is a hipStream_t passed as void*; dtype is OMR_F32 (0) or OMR_BF16 (1)
  * and names the activation/weight element type (accumulation is always fp32); "small vectors" (bias, LayerNorm
  * gamma/beta, statistics) are always fp32.  Encoder activations are NHWC; token matrices are row-major [rows][ld].
- * No hidden state: every call is re-entrant across streams.
+ * No hidden state: every call is re-entrant across streams and host threads (the only process-wide data are per-kernel
+ * launch constants -- resident blocks per CU, dynamic-LDS opt-in -- cached in atomics on first use; one process drives one GPU).
  */
 #ifndef OMR_HIP_H
 #define OMR_HIP_H
@@ -47,6 +48,10 @@ int omr_adam(float* p, const float* g, float* m, float* v, void* p_bf16, long n,
 /* greedy token pick: argmax(dim=-1) / topk(1) of the last-step logits (model.py:187,253), one row per decoded sample
  * (x [rows][ld], first n columns); first-index tie rule */
 int omr_argmax(const float* x, int rows, int n, long ld, long* idx_out, float* val_out, void* stream);
+/* weighted late fusion (src/multimodal/weighted_multimodal/test.py:50-61): the token of one decoding step of two unimodal models
+ * run in lock-step, argmax(alpha * softmax(logits_a) + (1 - alpha) * softmax(logits_b)) over fp32 rows of n logits, first-index
+ * tie rule; prob_out (nullable) receives the winning mixed probability.  alpha is rounded like the reference's Python float. */
+int omr_weighted_argmax(const float* logits_a, const float* logits_b, int n, float alpha, long* idx_out, float* prob_out, void* stream);
 /* audio front end (preprocessing.py:17-30): after the windowed DFT -- ONE omr_gemm of the centred,
  * hop-strided frames (lda = hop) against the Hann-weighted [cos | -sin] basis of the kept bins -- spec [frames][2*bins] holds
  * (re | im); this turns it into the reference's normalised log-spectrogram out [bins][frames] =
@@ -79,13 +84,19 @@ int omr_sw_align(const int* ref, int nr, const int* query, int nq, int match, in
 int omr_topk_logprob(const float* x, int rows, int n, long ld, int k, long* idx_out, float* val_out, void* stream);
 
 /* ---- normalisation ------------------------------------------------------------------------------------- */
-long omr_instnorm_workspace_bytes(int B, int C);
-/* nn.InstanceNorm2d(eps=1e-3, affine=False) statistics on x[B][HW][C] (encoder.py:151-156,174,232); the apply is
- * fused into the consumer conv (in_mean / in_rstd arguments below). */
+/* nn.InstanceNorm2d(eps=1e-3, affine=False) on x[B][HW][C] (encoder.py:151-156,174,232); the apply is fused into the consumer
+ * conv (in_mean / in_rstd arguments below).  Statistics are reduced DETERMINISTICALLY (bit-identical from run to run, like
+ * the reference's CPU path): every producer block stores fp64 partials into its own slot of workspace[B][slots][C][2] and
+ * the consumer adds an image's slots in index order -- no atomics.  workspace_bytes covers the slots plus the compact
+ * [B][C][2] sums the backward apply reads; slots = omr_instnorm_slots(B, HW) for the stand-alone passes
+ * (omr_instnorm_stats / omr_instnorm_bwd) or omr_conv3x3_stat_slots(B, Ho, Wo) when a conv epilogue is the producer
+ * (the caller zero-fills that workspace: a conv launch may use fewer blocks per image than there are slots). */
+int omr_instnorm_slots(int B, long HW);
+long omr_instnorm_workspace_bytes(int B, int C, int slots);
 int omr_instnorm_stats(int dtype, const void* x, float* mean, float* rstd, int B, long HW, int C, float eps, void* workspace, void* stream);
-int omr_instnorm_finalize(const void* workspace, float* mean, float* rstd, int B, long HW, int C, float eps, void* stream);
+int omr_instnorm_finalize(const void* workspace, int slots, float* mean, float* rstd, int B, long HW, int C, float eps, void* stream);
 int omr_instnorm_bwd_apply(int dtype, const void* dxhat, const void* x, const float* mean, const float* rstd, void* dx, int B, long HW, int C,
-                           int relu_mask, float relu_scale, const void* workspace, void* stream);
+                           int relu_mask, float relu_scale, void* workspace, int slots, void* stream);
 int omr_instnorm_bwd(int dtype, const void* dxhat, const void* x, const float* mean, const float* rstd, void* dx, int B, long HW, int C,
                      int relu_mask, float relu_scale, void* workspace, void* stream);
 /* post-norm residual with the sublayer dropout fused: out = LayerNorm(dropout(x) + res) (eps 1e-5), torch
@@ -127,7 +138,8 @@ int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, int N, int K
 int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const float* bias, void* y, const float* in_mean, const float* in_rstd,
                     const void* out_mask, float mask_scale, int B, int H, int W, int CIN, int COUT, int stride_h, int stride_w, int dil_h,
                     int dil_w, int Ho, int Wo, int relu, float drop_p, unsigned long long drop_seed, int drop_channel_mode,
-                    int stat_mode, double* stat_ws, const void* stat_x, const float* stat_mean, const float* stat_rstd, void* stream);
+                    int stat_mode, double* stat_ws, int stat_slots, const void* stat_x, const float* stat_mean, const float* stat_rstd,
+                    void* stream);
 int omr_conv3x3_weight_flip(int dtype, const void* w, void* wd, int COUT, int CIN, void* stream);
 /* dw[COUT][3][3][CIN] (fp32) += dy^T * im2col(x);  db[COUT] (nullable, fp32) += column sums of dy (bias gradient) */
 int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, const float* in_mean, const float* in_rstd, int B, int H, int W,
@@ -146,6 +158,10 @@ int omr_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, flo
 int omr_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                  long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
                  const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed, void* stream);
+/* Test / debug entry: the attention-probability dropout keep-mask (1 = kept) that omr_attn_fwd / omr_attn_bwd regenerate on
+ * the fly for (seed, dropout_p), one byte per score, mask[B][H][T][S].  Lets a checker inject the very same mask into a CPU
+ * restatement of nn.MultiheadAttention's dropout (tests/test_dropout_parity_gpu.py). */
+int omr_attn_dropout_mask(unsigned char* mask, int B, int H, int T, int S, float dropout_p, unsigned long long seed, void* stream);
 int omr_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta_ws,
                  void* dq, void* dk, void* dv, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, long bsq,
                  long bsk, long bsv, long bso, long bsdo, long bsdq, long bsdk, long bsdv, int B, int H, int T, int S, int head_dim,

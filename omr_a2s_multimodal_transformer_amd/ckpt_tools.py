@@ -26,11 +26,14 @@ def unimodal_state_dict(state_dict: Dict[str, torch.Tensor], modality: str) -> D
     """Keep `<modality>_encoder.*` / `<modality>_pos_2d.*` (prefix stripped) and `decoder.*`; drop the other modality's
     encoder / positional encoding and the `cross_attn.*` mixer (split_multimodal_ckpt.py:45-72)."""
     other = _other(modality)
-    out: Dict[str, torch.Tensor] = {}
-    for k, v in state_dict.items():
-        if k.startswith(f"{other}_encoder") or k.startswith(f"{other}_pos_2d") or k.startswith("cross_attn"):
-            continue
-        out[k.replace(f"{modality}_", "", 1) if k.startswith(f"{modality}_") else k] = v
+    kept = {k: v for k, v in state_dict.items()
+            if not (k.startswith(f"{other}_encoder") or k.startswith(f"{other}_pos_2d") or k.startswith("cross_attn"))}
+    # key ORDER as the reference leaves it (it pops each prefixed key and re-inserts the renamed one at the end,
+    # split_multimodal_ckpt.py:56-62): untouched keys first, renamed keys after them, each group in its original order
+    out: Dict[str, torch.Tensor] = {k: v for k, v in kept.items() if not k.startswith(f"{modality}_")}
+    for k, v in kept.items():
+        if k.startswith(f"{modality}_"):
+            out[k.replace(f"{modality}_", "", 1)] = v
     return out
 
 

@@ -647,6 +647,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         }
 }
 
+// Debug / test entry: materialise the keep-mask the three kernels above regenerate on the fly (1 = kept), one byte per score.
+__global__ void attn_dropout_mask_kernel(unsigned char* __restrict__ out, AttnArgs a) {
+    const long n = (long)a.B * a.H * a.T * a.S;
+    const uint32_t s2 = (uint32_t)(a.S + 1) >> 1, thr32 = a.drop_thresh << 16;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int key = (int)(i % a.S); long r = i / a.S;
+        const int q = (int)(r % a.T); r /= a.T;
+        const int h = (int)(r % a.H), b = (int)(r / a.H);
+        const uint32_t x = attn_rand2(attn_bh_key(a, b, h), (uint32_t)q * s2 + (uint32_t)(key >> 1));
+        out[i] = (a.drop_thresh == 0 || ((key & 1) ? attn_keep_hi(x, thr32) : attn_keep_lo(x, thr32))) ? 1 : 0;
+    }
+}
+
 template <typename T, int HD> int run_fwd(const AttnArgs& a, hipStream_t s) {
     if (a.T <= 32 && a.S > 64) {        // a single 32-row query block: split the keys over the waves instead
         hipLaunchKernelGGL((attn_fwd_kernel<T, HD, true>), dim3(1, a.H, a.B), dim3(256), 0, s, a);
@@ -682,6 +695,18 @@ int fill_common(AttnArgs& a, int B, int H, int T, int S, int hd, float dropout_p
 }
 
 }  // namespace
+
+extern "C" int omr_attn_dropout_mask(unsigned char* mask, int B, int H, int T, int S, float dropout_p, unsigned long long seed, void* stream) {
+    AttnArgs a = {};
+    int rc = fill_common(a, B, H, T, S, 64, dropout_p, seed, 0, -1, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if (!mask) return OMR_ERR_ARG;
+    const long n = (long)B * H * T * S;
+    long g = (n + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, mask, a);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
 
 extern "C" int omr_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                             long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,

@@ -10,6 +10,7 @@
 //   conv3x3_wgrad    dW[n][tap][c] += sum_pix dY[pix][n] X[pix+tap][c]  (MFMA, K = pixels, fp32 atomics)
 //   conv1_direct     the 1 -> 16 first layer (K = 9: HBM-bound, VALU) forward and weight gradient
 //   dwconv3x3        depthwise 3x3 forward / data gradient / weight gradient (HBM-bound, VALU)
+#include <atomic>
 #include <type_traits>
 
 #include "omr_common.h"
@@ -215,18 +216,18 @@ template <typename T, int TH, int CBN, int CBC, int SH, int SW> int launch_wgrad
     size_t shm = ((size_t)TH * TW * NP + (size_t)IH * IW * CP) * sizeof(T);
     if (shm > 160 * 1024) return OMR_ERR_UNSUPPORTED;
     auto kern = conv3x3_wgrad_kernel<T, TH, CBN, CBC, SH, SW>;
-    if (shm > 48 * 1024) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return OMR_ERR_LAUNCH;
-    }
     const int gy = cdiv(a.COUT, CBN) * cdiv(a.CIN, CBC);
     const int ntiles = a.B * a.tiles_h * a.tiles_w;
-    static int occ_cache = 0;            // resident blocks per CU of this instantiation: the persistent grid fills the chip once
-    if (occ_cache == 0) {
+    static std::atomic<int> occ_cache{0};   // resident blocks per CU of this instantiation (0 -> value once; see conv3x3_mfma.h)
+    int occv = occ_cache.load(std::memory_order_acquire);
+    if (occv == 0) {
+        if (shm > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return OMR_ERR_LAUNCH;
         int occ = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, shm) != hipSuccess || occ < 1) occ = 2;
-        occ_cache = occ;
+        occv = occ;
+        occ_cache.store(occ, std::memory_order_release);
     }
-    int gx = (256 * occ_cache + gy - 1) / gy; if (gx < 1) gx = 1; if (gx > ntiles) gx = ntiles;
+    int gx = (256 * occv + gy - 1) / gy; if (gx < 1) gx = 1; if (gx > ntiles) gx = ntiles;
     hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), shm, s, a);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
@@ -663,14 +664,14 @@ inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g < 1 ? 1 : 
 extern "C" int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const float* bias, void* y, const float* in_mean, const float* in_rstd,
                                const void* out_mask, float mask_scale, int B, int H, int W, int CIN, int COUT, int stride_h, int stride_w,
                                int dil_h, int dil_w, int Ho, int Wo, int relu, float drop_p, unsigned long long drop_seed,
-                               int drop_channel_mode, int stat_mode, double* stat_ws, const void* stat_x, const float* stat_mean,
-                               const float* stat_rstd, void* stream) {
+                               int drop_channel_mode, int stat_mode, double* stat_ws, int stat_slots, const void* stat_x,
+                               const float* stat_mean, const float* stat_rstd, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0 || CIN <= 0 || COUT <= 0 || !x || !w || !y) return OMR_ERR_ARG;
     if (stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1 || dil_h > 2 || dil_w > 2) return OMR_ERR_ARG;
     if ((stride_h > 1 || stride_w > 1) && (dil_h > 1 || dil_w > 1)) return OMR_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     if (drop_p < 0.f || drop_p >= 1.f || stat_mode < 0 || stat_mode > 2) return OMR_ERR_ARG;
-    if (stat_mode && !stat_ws) return OMR_ERR_ARG;
+    if (stat_mode && (!stat_ws || stat_slots < 1)) return OMR_ERR_ARG;
     if (stat_mode == 2 && (!stat_x || !stat_mean || !stat_rstd)) return OMR_ERR_ARG;
     if (CIN == 1) {
         if (drop_p > 0.f || stat_mode) return OMR_ERR_UNSUPPORTED;
@@ -691,10 +692,18 @@ extern "C" int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const fl
     a.sh = stride_h; a.sw = stride_w; a.dh = dil_h; a.dw = dil_w; a.relu = relu; a.tiles_w = a.tiles_h = 0;
     a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_scale = 1.f / (1.f - drop_p); a.drop_seed = drop_seed;
     a.drop_channel = drop_channel_mode;
-    a.stat_mode = stat_mode; a.stat_ws = stat_ws; a.stat_x = stat_x; a.stat_mean = stat_mean; a.stat_rstd = stat_rstd;
+    a.stat_mode = stat_mode; a.stat_ws = stat_ws; a.stat_x = stat_x; a.stat_mean = stat_mean; a.stat_rstd = stat_rstd; a.stat_slots = stat_slots;
     if (dtype == OMR_BF16) return omr_conv3x3_dispatch_bf16(a, s);
     if (dtype == OMR_F32) return omr_conv3x3_dispatch_f32(a, s);
     return OMR_ERR_UNSUPPORTED;
+}
+
+/* upper bound on the blocks per image of the persistent conv grid (<= 8 resident 256-thread blocks per CU on 256 CUs, and
+ * never more than the 4-row x 32-column tiles of an image): the slot count of the fused-statistics workspace */
+extern "C" int omr_conv3x3_stat_slots(int B, int Ho, int Wo) {
+    if (B <= 0 || Ho <= 0 || Wo <= 0) return OMR_ERR_ARG;
+    const long tiles = (long)cdiv(Ho, 4) * cdiv(Wo, TW), slots = (256L * 8 + B - 1) / B;
+    return (int)(tiles < slots ? tiles : slots);
 }
 
 extern "C" int omr_conv3x3_weight_flip(int dtype, const void* w, void* wd, int COUT, int CIN, void* stream) {

@@ -1,6 +1,7 @@
 // conv3x3 implicit-GEMM kernel (forward and data gradient) -- shared by conv_bf16.hip / conv_f32.hip so the two dtypes
 // compile in parallel.  See conv.hip for the overview.
 #pragma once
+#include <atomic>
 #include <type_traits>
 
 #include "omr_common.h"
@@ -46,7 +47,10 @@ struct ConvArgs {
     // fused per-(image, channel) reductions over the STORED output tile (fp64 accumulators stat_ws[B][COUT][2]):
     //   mode 1: {sum y, sum y^2}            -> InstanceNorm statistics of this conv's output (encoder.py:174)
     //   mode 2: {sum g, sum g * xhat}       -> InstanceNorm backward sums, xhat = (stat_x - mean) * rstd at the same position
-    int stat_mode; double* stat_ws; const void* stat_x; const float* stat_mean; const float* stat_rstd;
+    // The reduction is DETERMINISTIC: per-thread fp32 partials (fixed tile walk) -> fixed-order fp64 sum over the block's
+    // threads -> plain store into the block's own slot stat_ws[b][blockIdx.x][COUT][2]; the consumer (omr_instnorm_finalize /
+    // omr_instnorm_bwd_apply) adds the stat_slots slots of an image in index order.  No atomics anywhere.
+    int stat_mode; double* stat_ws; const void* stat_x; const float* stat_mean; const float* stat_rstd; int stat_slots;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -117,9 +121,9 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? (CK == 16 ? 4 : 3) : 2)
 
     if (single) stage_weights(0);
 
-    // fused reductions: this thread always stores the same VEC-channel chunk, so it keeps fp32 partials in registers and the
-    // block flushes them (LDS -> one fp64 atomic per channel) only when its tile range moves on to another image
-    __shared__ float sred[EPI ? 2 * NT : 4];
+    // fused reductions: this thread always stores the same VEC-channel chunk, so it keeps fp32 partials in registers; when the
+    // block is done with its (single) image the partials are combined in a FIXED order through LDS (the staging tiles are
+    // dead by then) and stored into the block's own slot of the fp64 workspace -- bit-identical from run to run.
     constexpr int CPO = NT / VEC;
     constexpr int NSV = EPI ? VEC : 1;
     float ssum[NSV], ssq[NSV], smu[NSV], srs[NSV];
@@ -127,22 +131,25 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? (CK == 16 ? 4 : 3) : 2)
     for (int e = 0; e < NSV; ++e) { ssum[e] = ssq[e] = 0.f; smu[e] = 0.f; srs[e] = 1.f; }
     const bool stat1 = EPI == 1 && a.stat_mode == 1, stat2 = EPI == 2 && a.stat_mode == 2;
     auto flush_stats = [&](int bimg) {
-        if constexpr (EPI == 0) return;
-        for (int i = tid; i < 2 * NT; i += 256) sred[i] = 0.f;
-        __syncthreads();
-        const int kcs = (tid % CPO) * VEC;
+        if constexpr (EPI != 0) {
+            constexpr int NGRP = 256 / CPO;                       // threads that share a channel chunk
+            static_assert((size_t)NGRP * 2 * NT * sizeof(float) <= ((size_t)XS_ELEMS + (size_t)NT * 9 * CKP) * sizeof(T), "reduction scratch fits in the (dead) halo + weight tiles");
+            float* red = reinterpret_cast<float*>(smem_raw);      // [NGRP][NT][2]
+            __syncthreads();                                      // the last tile's store loop is done with Os
+            const int kcs = (tid % CPO) * VEC, grp = tid / CPO;
 #pragma unroll
-        for (int e = 0; e < NSV; ++e) {
-            atomicAdd(&sred[(kcs + e) * 2], ssum[e]);
-            atomicAdd(&sred[(kcs + e) * 2 + 1], ssq[e]);
-            ssum[e] = ssq[e] = 0.f;
+            for (int e = 0; e < NSV; ++e) {
+                red[(grp * NT + kcs + e) * 2] = ssum[e];
+                red[(grp * NT + kcs + e) * 2 + 1] = ssq[e];
+            }
+            __syncthreads();
+            for (int i = tid; i < 2 * NT; i += 256) {
+                const int n = n0 + (i >> 1);
+                double acc2 = 0.0;
+                for (int g = 0; g < NGRP; ++g) acc2 += (double)red[g * 2 * NT + i];
+                if (n < a.COUT) a.stat_ws[(((long)bimg * a.stat_slots + blockIdx.x) * a.COUT + n) * 2 + (i & 1)] = acc2;
+            }
         }
-        __syncthreads();
-        for (int i = tid; i < 2 * NT; i += 256) {
-            const int n = n0 + (i >> 1);
-            if (n < a.COUT) atomicAdd(&a.stat_ws[((long)bimg * a.COUT + n) * 2 + (i & 1)], (double)sred[i]);
-        }
-        __syncthreads();
     };
 
     // persistent schedule: blockIdx.z = image; the gridDim.x blocks of an image walk its tiles with stride gridDim.x, so
@@ -377,21 +384,27 @@ template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, b
     if (a.COUT % Frag<T>::N) return OMR_ERR_UNSUPPORTED;
     if (a.mean && a.CIN > NORM_MAX) return OMR_ERR_UNSUPPORTED;
     auto kern = conv3x3_mfma_kernel<T, NT, RPW, CK, SH, SW, DH, DW, SINGLE, EPI>;
-    if (shm > 48 * 1024) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return OMR_ERR_LAUNCH;
-    }
     const int ny = cdiv(a.COUT, NT);
     const long tiles_per_img = (long)a.tiles_w * a.tiles_h;
     // persistent grid = the block slots the chip really has for this kernel (256 CUs x resident blocks per CU), split
-    // evenly over the images: every block is resident from the start, no tail of queued blocks
-    static int occ_cache = 0;
-    if (occ_cache == 0) {
+    // evenly over the images: every block is resident from the start, no tail of queued blocks.  The per-instantiation
+    // launch constants (dynamic-LDS opt-in, resident blocks per CU) are looked up once; the cache is an atomic whose only
+    // transition is 0 -> value, and racing first calls compute the same value (one process drives one GPU).
+    static std::atomic<int> occ_cache{0};
+    int occv = occ_cache.load(std::memory_order_acquire);
+    if (occv == 0) {
+        if (shm > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return OMR_ERR_LAUNCH;
         int occ = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, shm) != hipSuccess || occ < 1) occ = 2;
-        occ_cache = occ;
+        occv = occ;
+        occ_cache.store(occ, std::memory_order_release);
     }
-    long gx = (256L * occ_cache + (long)ny * a.B - 1) / ((long)ny * a.B);
+    long gx = (256L * occv + (long)ny * a.B - 1) / ((long)ny * a.B);
     if (gx > tiles_per_img) gx = tiles_per_img;
+    if (a.stat_mode) {                       // one workspace slot per block of an image
+        if (a.stat_slots < 1) return OMR_ERR_ARG;
+        if (gx > a.stat_slots) gx = a.stat_slots;
+    }
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, ny, a.B), dim3(256), shm, s, a);
     OMR_CHECK_LAUNCH();

@@ -15,6 +15,7 @@
 //     fetched them.
 //   * Fused: bias gradient (column sums of the staged dY tile) and, for the strided convs that normalise on load
 //     (ConvBlock conv3, encoder.py:151-156), the InstanceNorm-apply as an in-place LDS pass over the landed X tile.
+#include <atomic>
 #include "omr_common.h"
 #include "omr_hip.h"
 
@@ -326,18 +327,20 @@ template <int CBN, int CBC, int TH, int SH, int SW, int NW, int NSTAGE, bool NOR
                            1024 + (NORM ? 8 * 512 : 0);
     static_assert(shm <= 160 * 1024, "LDS ring does not fit");
     auto kern = wgrad_dma_kernel<CBN, CBC, TH, SH, SW, NW, NSTAGE, NORM>;
-    static int occ_cache = 0;            // resident blocks per CU of this instantiation: the persistent grid fills the chip once
-    if (occ_cache == 0) {
+    static std::atomic<int> occ_cache{0};   // resident blocks per CU of this instantiation (0 -> value once; see conv3x3_mfma.h)
+    int occv = occ_cache.load(std::memory_order_acquire);
+    if (occv == 0) {
         if (shm > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
             return OMR_ERR_LAUNCH;
         int occ = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, NW * 64, shm) != hipSuccess || occ < 1) occ = 1;
-        occ_cache = occ;
+        occv = occ;
+        occ_cache.store(occ, std::memory_order_release);
     }
     const int gy = cdiv(a.COUT, CBN) * cdiv(a.CIN, CBC);
     const int ntiles = a.B * a.tiles_h * a.tiles_w;
     if ((long)a.B * a.tiles_h * a.tiles_w >= (1 << 23) || (long)IH * a.Wr * a.CIN >= (1L << 30)) return OMR_ERR_UNSUPPORTED;   // fdiv / 32-bit offsets
-    int gx = (NUM_CU * occ_cache + gy - 1) / gy; if (gx < 1) gx = 1; if (gx > ntiles) gx = ntiles;
+    int gx = (NUM_CU * occv + gy - 1) / gy; if (gx < 1) gx = 1; if (gx > ntiles) gx = ntiles;
     hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NW * 64), shm, s, a);
     OMR_CHECK_LAUNCH();
     return OMR_OK;

@@ -178,6 +178,47 @@ __global__ void argmax_kernel(const float* __restrict__ x0, int n, long ld, long
     if (threadIdx.x == 0) { idx_out[0] = si[0]; if (val_out) val_out[0] = sv[0]; }
 }
 
+// ---------------------------------------------------------------- weighted late fusion (weighted_multimodal/test.py:50-61)
+// token = argmax(alpha * softmax(la) + (1 - alpha) * softmax(lb)), first-index tie rule; also returns the mixed probability.
+// One workgroup, three passes over the two logit rows (V <= a few thousand: L2-resident).  The mix is two roundings of
+// products plus one add like torch's `alpha * p + (1 - alpha) * q` (no fma contraction), so ties break the same way.
+__global__ void weighted_argmax_kernel(const float* __restrict__ la, const float* __restrict__ lb, int n, float wa, float wb,
+                                       long* __restrict__ idx_out, float* __restrict__ prob_out) {
+    __shared__ float sa[256], sb[256];
+    __shared__ int si[256];
+    const int tid = threadIdx.x;
+    float ma = -INFINITY, mb = -INFINITY;
+    for (int i = tid; i < n; i += 256) { ma = fmaxf(ma, la[i]); mb = fmaxf(mb, lb[i]); }
+    sa[tid] = ma; sb[tid] = mb;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) { sa[tid] = fmaxf(sa[tid], sa[tid + o]); sb[tid] = fmaxf(sb[tid], sb[tid + o]); } __syncthreads(); }
+    ma = sa[0]; mb = sb[0];
+    __syncthreads();
+    float ea = 0.f, eb = 0.f;
+    for (int i = tid; i < n; i += 256) { ea += expf(la[i] - ma); eb += expf(lb[i] - mb); }
+    sa[tid] = ea; sb[tid] = eb;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) { sa[tid] += sa[tid + o]; sb[tid] += sb[tid + o]; } __syncthreads(); }
+    const float za = sa[0], zb = sb[0];
+    __syncthreads();
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int i = tid; i < n; i += 256) {
+        const float pa = expf(la[i] - ma) / za, pb = expf(lb[i] - mb) / zb;
+        const float v = __fadd_rn(__fmul_rn(wa, pa), __fmul_rn(wb, pb));
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+    sa[tid] = best; si[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float v2 = sa[tid + o]; const int i2 = si[tid + o];
+            if (v2 > sa[tid] || (v2 == sa[tid] && i2 < si[tid])) { sa[tid] = v2; si[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { idx_out[0] = si[0]; if (prob_out) prob_out[0] = sa[0]; }
+}
+
 // ---------------------------------------------------------------- top-k log-probabilities per row (beam search)
 // out_val[row][j] = log_softmax(x[row])[out_idx[row][j]], j-th largest, ties broken towards the smaller index (so k = 1 is
 // argmax_kernel's pick).  One workgroup per row: a max / sum-exp pass, then k selection passes over the candidates that
@@ -366,6 +407,14 @@ extern "C" int omr_log_stft_post(float* spec, long frames, int bins, unsigned* m
 extern "C" int omr_topk_logprob(const float* x, int rows, int n, long ld, int k, long* idx_out, float* val_out, void* stream) {
     if (n <= 0 || rows <= 0 || ld < n || k <= 0 || k > n || !idx_out || !val_out) return OMR_ERR_ARG;
     hipLaunchKernelGGL(topk_logprob_kernel, rows, 256, 0, (hipStream_t)stream, x, n, ld, k, idx_out, val_out);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_weighted_argmax(const float* logits_a, const float* logits_b, int n, float alpha, long* idx_out, float* prob_out, void* stream) {
+    if (n <= 0 || !logits_a || !logits_b || !idx_out) return OMR_ERR_ARG;
+    // the reference multiplies fp32 tensors by the Python floats alpha and (1 - alpha): each is rounded to fp32 once
+    hipLaunchKernelGGL(weighted_argmax_kernel, 1, 256, 0, (hipStream_t)stream, logits_a, logits_b, n, alpha, (float)(1.0 - (double)alpha), idx_out, prob_out);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }

@@ -8,20 +8,19 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------
 // InstanceNorm statistics over x[B][HW][C] (NHWC): per (b, c) mean and 1/sqrt(biased var + eps).
-// Stage 1: each block reduces a slab of pixels for all channels; per-thread fp32 partials over a
-// short run, then fp64 atomics into ws[b][c][2] (sum, sum of squares).  Stage 2 finalises.
+// DETERMINISTIC two-stage reduction (no atomics): stage 1 -- each block reduces a slab of pixels for all channels (per-thread
+// fp32 partials over a short run, combined over the block's threads in a fixed order in fp64) and stores the result into
+// its own slot ws[b][slot][c][2] = (sum, sum of squares); stage 2 adds an image's slots in index order and finalises.
+// The same slot layout is written by the conv kernels' fused statistics epilogue (conv3x3_mfma.h).
 // The apply is fused into the consumer's tile load (conv3 / depthwise conv3), never materialised.
-// Thread t owns channel group (t % (C/VEC)) and walks pixels with 16-byte loads (fully coalesced: NHWC rows are
-// contiguous).  Per-thread fp32 partials over a short run -> LDS fp32 per-block sums -> one fp64 atomic per channel.
+// Thread t owns channel group (t % (C/VEC)) and walks pixels with 16-byte loads (fully coalesced: NHWC rows are contiguous).
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void instnorm_partial_kernel(const T* __restrict__ x, const T* __restrict__ g, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, double* __restrict__ ws, long HW, int C,
                                                                int pix_per_block) {
     typedef typename Frag<T>::type F;
     constexpr int VEC = Frag<T>::N;
-    extern __shared__ __attribute__((aligned(16))) float red[];   // [C][2]
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
-    __syncthreads();
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [nphase][C][2]
     const int b = blockIdx.y;
     const int ncg = C / VEC;                       // channel groups; divides blockDim for the encoder's widths
     const int cg = threadIdx.x % ncg, phase = threadIdx.x / ncg, nphase = blockDim.x / ncg;
@@ -35,43 +34,64 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const T* __restri
         mu[e] = BWD ? mean[(long)b * C + cg * VEC + e] : 0.f;
         rs[e] = BWD ? rstd[(long)b * C + cg * VEC + e] : 1.f;
     }
-    if (phase < nphase) {
-        for (long p = p0 + phase; p < p1; p += nphase) {
-            const F xv = *reinterpret_cast<const F*>(x + base + p * C + cg * VEC);
-            if (BWD) {
-                const F gv = *reinterpret_cast<const F*>(g + base + p * C + cg * VEC);
+    for (long p = p0 + phase; p < p1; p += nphase) {
+        const F xv = *reinterpret_cast<const F*>(x + base + p * C + cg * VEC);
+        if (BWD) {
+            const F gv = *reinterpret_cast<const F*>(g + base + p * C + cg * VEC);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const float gg = to_f32(gv[e]);
-                    s[e] += gg;
-                    q[e] += gg * ((to_f32(xv[e]) - mu[e]) * rs[e]);
-                }
-            } else {
+            for (int e = 0; e < VEC; ++e) {
+                const float gg = to_f32(gv[e]);
+                s[e] += gg;
+                q[e] += gg * ((to_f32(xv[e]) - mu[e]) * rs[e]);
+            }
+        } else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const float v = to_f32(xv[e]);
-                    s[e] += v;
-                    q[e] += v * v;
-                }
+            for (int e = 0; e < VEC; ++e) {
+                const float v = to_f32(xv[e]);
+                s[e] += v;
+                q[e] += v * v;
             }
         }
+    }
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            atomicAdd(&red[(cg * VEC + e) * 2 + 0], s[e]);
-            atomicAdd(&red[(cg * VEC + e) * 2 + 1], q[e]);
-        }
+    for (int e = 0; e < VEC; ++e) {
+        red[(phase * C + cg * VEC + e) * 2 + 0] = s[e];
+        red[(phase * C + cg * VEC + e) * 2 + 1] = q[e];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&ws[(long)b * C * 2 + i], (double)red[i]);
+    double* out = ws + ((long)b * gridDim.x + blockIdx.x) * C * 2;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        double acc = 0.0;
+        for (int ph = 0; ph < nphase; ++ph) acc += (double)red[ph * 2 * C + i];
+        out[i] = acc;
+    }
 }
-__global__ void instnorm_finalize_kernel(const double* __restrict__ ws, float* __restrict__ mean, float* __restrict__ rstd, long n, double inv_hw, float eps) {
+// sums[b][c][2] = sum over the image's slots, in slot order (fixed): one thread per (b, c)
+__device__ __forceinline__ void slot_sums(const double* __restrict__ ws, long i, int C, int slots, double& s0, double& s1) {
+    const long b = i / C; const int c = (int)(i % C);
+    const double* p = ws + (b * slots * C + c) * 2;
+    s0 = 0.0; s1 = 0.0;
+    for (int k = 0; k < slots; ++k) { s0 += p[(long)k * C * 2]; s1 += p[(long)k * C * 2 + 1]; }
+}
+__global__ void instnorm_finalize_kernel(const double* __restrict__ ws, int slots, int C, float* __restrict__ mean, float* __restrict__ rstd, long n,
+                                         double inv_hw, float eps) {
     long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    double m = ws[2 * i] * inv_hw;
-    double var = ws[2 * i + 1] * inv_hw - m * m;
+    double s0, s1;
+    slot_sums(ws, i, C, slots, s0, s1);
+    double m = s0 * inv_hw;
+    double var = s1 * inv_hw - m * m;
     if (var < 0) var = 0;
     mean[i] = (float)m;
     rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+// compact[b][c][2] (the tail of the workspace) = slot sums: what the backward apply kernel reads
+__global__ void instnorm_collapse_kernel(const double* __restrict__ ws, int slots, int C, double* __restrict__ compact, long n) {
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s0, s1;
+    slot_sums(ws, i, C, slots, s0, s1);
+    compact[2 * i] = s0; compact[2 * i + 1] = s1;
 }
 
 // InstanceNorm backward.  With xhat = (x - mean) * rstd and g = dL/dxhat:
@@ -259,68 +279,72 @@ static int stat_pixels_per_block(long HW, int B) {
     while (ppb > 64 && cdiv(HW, ppb) * (long)B < 1024) ppb /= 2;
     return (int)ppb;
 }
+static size_t partial_lds_bytes(int dtype) { return (size_t)256 * (dtype == OMR_BF16 ? 8 : 4) * 2 * sizeof(float); }   // [nphase][C][2] with nphase * C/VEC = 256
 
-extern "C" long omr_instnorm_workspace_bytes(int B, int C) { return (long)B * C * 2 * sizeof(double); }
+/* slots per image of the stand-alone statistics passes (omr_instnorm_stats / omr_instnorm_bwd) */
+extern "C" int omr_instnorm_slots(int B, long HW) { return (B <= 0 || HW <= 0) ? OMR_ERR_ARG : cdiv(HW, stat_pixels_per_block(HW, B)); }
+/* bytes of a statistics workspace with `slots` slots per image: partials [B][slots][C][2] + compact sums [B][C][2], fp64 */
+extern "C" long omr_instnorm_workspace_bytes(int B, int C, int slots) { return ((long)B * slots * C * 2 + (long)B * C * 2) * sizeof(double); }
 
 extern "C" int omr_instnorm_stats(int dtype, const void* x, float* mean, float* rstd, int B, long HW, int C, float eps, void* workspace,
                                   void* stream) {
     if (B <= 0 || HW <= 0 || C <= 0 || !workspace) return OMR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, omr_instnorm_workspace_bytes(B, C), s) != hipSuccess) return OMR_ERR_LAUNCH;
     const int vec = dtype == OMR_BF16 ? 8 : 4;
     if (C % vec || 256 % (C / vec)) return OMR_ERR_UNSUPPORTED;
     int ppb = stat_pixels_per_block(HW, B);
     dim3 grid(cdiv(HW, ppb), B);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_partial_kernel<T, false>), grid, 256, 2 * C * sizeof(float), s, (const T*)x, (const T*)nullptr,
+    DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_partial_kernel<T, false>), grid, 256, partial_lds_bytes(dtype), s, (const T*)x, (const T*)nullptr,
                                          (const float*)nullptr, (const float*)nullptr, (double*)workspace, HW, C, ppb));
     long n = (long)B * C;
-    hipLaunchKernelGGL(instnorm_finalize_kernel, cdiv(n, 256), 256, 0, s, (const double*)workspace, mean, rstd, n, 1.0 / (double)HW, eps);
+    hipLaunchKernelGGL(instnorm_finalize_kernel, cdiv(n, 256), 256, 0, s, (const double*)workspace, (int)grid.x, C, mean, rstd, n, 1.0 / (double)HW, eps);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }
 
-/* mean / rstd from fp64 {sum, sum of squares} accumulators that a producer kernel filled (omr_conv3x3_fwd stat_mode 1) */
-extern "C" int omr_instnorm_finalize(const void* workspace, float* mean, float* rstd, int B, long HW, int C, float eps, void* stream) {
-    if (B <= 0 || HW <= 0 || C <= 0 || !workspace) return OMR_ERR_ARG;
+/* mean / rstd from the fp64 {sum, sum of squares} slots that a producer kernel filled (omr_conv3x3_fwd stat_mode 1) */
+extern "C" int omr_instnorm_finalize(const void* workspace, int slots, float* mean, float* rstd, int B, long HW, int C, float eps, void* stream) {
+    if (B <= 0 || HW <= 0 || C <= 0 || slots < 1 || !workspace) return OMR_ERR_ARG;
     long n = (long)B * C;
-    hipLaunchKernelGGL(instnorm_finalize_kernel, cdiv(n, 256), 256, 0, (hipStream_t)stream, (const double*)workspace, mean, rstd, n, 1.0 / (double)HW, eps);
+    hipLaunchKernelGGL(instnorm_finalize_kernel, cdiv(n, 256), 256, 0, (hipStream_t)stream, (const double*)workspace, slots, C, mean, rstd, n, 1.0 / (double)HW, eps);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }
 
-/* apply step of the InstanceNorm backward with {sum g, sum g*xhat} already accumulated in `workspace`
- * (omr_conv3x3_fwd stat_mode 2 fuses that reduction into the data-gradient conv that produces dxhat) */
-extern "C" int omr_instnorm_bwd_apply(int dtype, const void* dxhat, const void* x, const float* mean, const float* rstd, void* dx, int B, long HW,
-                                      int C, int relu_mask, float relu_scale, const void* workspace, void* stream) {
-    if (B <= 0 || HW <= 0 || C <= 0 || !workspace) return OMR_ERR_ARG;
-    const int vec = dtype == OMR_BF16 ? 8 : 4;
-    if (C % vec || 256 % (C / vec)) return OMR_ERR_UNSUPPORTED;
+static int launch_bwd_apply(int dtype, const void* dxhat, const void* x, const float* mean, const float* rstd, void* dx, int B, long HW, int C,
+                            int relu_mask, float relu_scale, double* ws, int slots, hipStream_t s) {
+    double* compact = ws + (long)B * slots * C * 2;
+    long n = (long)B * C;
+    hipLaunchKernelGGL(instnorm_collapse_kernel, cdiv(n, 256), 256, 0, s, (const double*)ws, slots, C, compact, n);
     int ppb2 = 1024;
     dim3 grid2(cdiv(HW, ppb2), B);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), grid2, 256, 0, (hipStream_t)stream, (const T*)dxhat, (const T*)x, mean, rstd,
-                                         (const double*)workspace, (T*)dx, HW, C, ppb2, (float)(1.0 / (double)HW), relu_mask, relu_scale));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), grid2, 256, 0, s, (const T*)dxhat, (const T*)x, mean, rstd,
+                                         (const double*)compact, (T*)dx, HW, C, ppb2, (float)(1.0 / (double)HW), relu_mask, relu_scale));
     OMR_CHECK_LAUNCH();
     return OMR_OK;
+}
+
+/* apply step of the InstanceNorm backward with {sum g, sum g*xhat} already in the slots of `workspace`
+ * (omr_conv3x3_fwd stat_mode 2 fuses that reduction into the data-gradient conv that produces dxhat) */
+extern "C" int omr_instnorm_bwd_apply(int dtype, const void* dxhat, const void* x, const float* mean, const float* rstd, void* dx, int B, long HW,
+                                      int C, int relu_mask, float relu_scale, void* workspace, int slots, void* stream) {
+    if (B <= 0 || HW <= 0 || C <= 0 || slots < 1 || !workspace) return OMR_ERR_ARG;
+    const int vec = dtype == OMR_BF16 ? 8 : 4;
+    if (C % vec || 256 % (C / vec)) return OMR_ERR_UNSUPPORTED;
+    return launch_bwd_apply(dtype, dxhat, x, mean, rstd, dx, B, HW, C, relu_mask, relu_scale, (double*)workspace, slots, (hipStream_t)stream);
 }
 
 extern "C" int omr_instnorm_bwd(int dtype, const void* dxhat, const void* x, const float* mean, const float* rstd, void* dx, int B, long HW,
                                 int C, int relu_mask, float relu_scale, void* workspace, void* stream) {
     if (B <= 0 || HW <= 0 || C <= 0 || !workspace) return OMR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, omr_instnorm_workspace_bytes(B, C), s) != hipSuccess) return OMR_ERR_LAUNCH;
     const int vec = dtype == OMR_BF16 ? 8 : 4;
     if (C % vec || 256 % (C / vec)) return OMR_ERR_UNSUPPORTED;
     int ppb = stat_pixels_per_block(HW, B);
     dim3 grid(cdiv(HW, ppb), B);
-    int ppb2 = 1024;
-    dim3 grid2(cdiv(HW, ppb2), B);
-    DISPATCH_T(dtype, {
-        hipLaunchKernelGGL((instnorm_partial_kernel<T, true>), grid, 256, 2 * C * sizeof(float), s, (const T*)x, (const T*)dxhat, mean, rstd, (double*)workspace, HW, C, ppb);
-        hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), grid2, 256, 0, s, (const T*)dxhat, (const T*)x, mean, rstd, (const double*)workspace,
-                           (T*)dx, HW, C, ppb2, (float)(1.0 / (double)HW), relu_mask, relu_scale);
-    });
-    OMR_CHECK_LAUNCH();
-    return OMR_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_partial_kernel<T, true>), grid, 256, partial_lds_bytes(dtype), s, (const T*)x, (const T*)dxhat, mean, rstd,
+                                         (double*)workspace, HW, C, ppb));
+    return launch_bwd_apply(dtype, dxhat, x, mean, rstd, dx, B, HW, C, relu_mask, relu_scale, (double*)workspace, (int)grid.x, s);
 }
 
 #define LN_DISPATCH_PER(KERNEL, ...)                                                                       \

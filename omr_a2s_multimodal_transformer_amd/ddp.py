@@ -33,9 +33,21 @@ class GradReducer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.buckets: List[Tuple[int, int]] = list(buckets) if buckets else [(0, flat.total)]
         self.done = [False] * len(self.buckets)
+        self._backwards = 0               # GradBoundary crossings since the last finish()
         self.handles: List = []
         self.use_stream = async_stream and flat.grad.is_cuda
         self.stream = torch.cuda.Stream(device=flat.device) if self.use_stream else None
+
+    def broadcast_state(self) -> None:
+        """Rank 0's master parameters (and Adam moments, if an optimizer exists already) to every rank, then refresh the bf16
+        compute copy: what DistributedDataParallel does at construction, so replicas are equal whatever each rank seeded or
+        loaded."""
+        if self.world == 1:
+            return
+        for t in (self.flat.master, self.flat.exp_avg, self.flat.exp_avg_sq):
+            if t is not None:
+                dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        self.flat.sync_lowp()
 
     @property
     def grad_scale(self) -> float:
@@ -43,8 +55,14 @@ class GradReducer:
         return 1.0 / self.world
 
     def reduce_bucket(self, i: int) -> None:
-        """Enqueue bucket i's all-reduce (idempotent per step)."""
-        if self.world == 1 or self.done[i]:
+        """Enqueue bucket i's all-reduce (idempotent per step: a second backward before finish() -- gradient accumulation --
+        would add to a bucket that is already on the wire, so it is refused rather than silently mis-reduced)."""
+        if self.world == 1:
+            return
+        if self.done[i]:
+            if self._backwards > 1:
+                raise RuntimeError("GradReducer: a second backward reached an already reduced bucket; call finish() (and the optimizer) "
+                                   "after every backward -- gradient accumulation across backwards is not supported")
             return
         self.done[i] = True
         WgradStream.join()                     # weight gradients issued on the side stream belong to the bucket too
@@ -69,6 +87,7 @@ class GradReducer:
             h.wait()
         self.handles.clear()
         self.done = [False] * len(self.buckets)
+        self._backwards = 0
 
 
 class GradBoundary(Function):
@@ -87,6 +106,7 @@ class GradBoundary(Function):
     @staticmethod
     def backward(ctx, *gs):
         if ctx.reducer is not None:
+            ctx.reducer._backwards += 1
             for i in ctx.bucket_ids:
                 ctx.reducer.reduce_bucket(i)
         return (None, None) + tuple(gs)
@@ -104,3 +124,32 @@ def shard_indices(n_samples: int, rank: int, world: int, epoch: int = 0, shuffle
     total = (n_samples + world - 1) // world * world
     idx += idx[: total - n_samples]
     return idx[rank:total:world]
+
+
+class ShardedLoader:
+    """What Lightning's DDP does to the reference's DataLoaders: a DistributedSampler over the SAMPLES
+    (shard_indices: shared-seed shuffle per epoch, wrap-around padding, rank r takes r::world) followed by batching and the
+    collate function (preprocessing.py:85-144).  `dataset` is any sequence of samples; call set_epoch(e) before each epoch
+    (Trainer.fit does).  With world == 1 it is a plain (optionally shuffled) batched loader."""
+
+    def __init__(self, dataset, batch_size: int, collate_fn, rank: Optional[int] = None, world: Optional[int] = None, shuffle: bool = True,
+                 seed: int = 0):
+        init = dist.is_available() and dist.is_initialized()
+        self.dataset, self.batch_size, self.collate_fn, self.shuffle, self.seed = dataset, batch_size, collate_fn, shuffle, seed
+        self.rank = rank if rank is not None else (dist.get_rank() if init else 0)
+        self.world = world if world is not None else (dist.get_world_size() if init else 1)
+        self.epoch = 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def indices(self) -> List[int]:
+        return shard_indices(len(self.dataset), self.rank, self.world, self.epoch, self.shuffle, self.seed)
+
+    def __len__(self) -> int:
+        return (len(self.indices()) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        idx = self.indices()
+        for i in range(0, len(idx), self.batch_size):
+            yield self.collate_fn([self.dataset[j] for j in idx[i:i + self.batch_size]])

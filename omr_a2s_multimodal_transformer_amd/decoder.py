@@ -27,7 +27,7 @@ def sinusoid_1d(max_len: int, emb_dim: int) -> torch.Tensor:
 def _dropout(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
     if not training or p <= 0.0:
         return x
-    return Fn.DropoutFn.apply(x, p, next_seed(), False, False)
+    return Fn.DropoutFn.apply(x, p, next_seed("rows", p), False, False)
 
 
 class PositionalEncoding1D(nn.Module):
@@ -92,7 +92,7 @@ class MultiheadAttention(nn.Module):
     def self_attention(self, x, causal: bool, window: int, key_bias, training: bool):
         qkv = Fn.linear(x, self.in_proj_weight, self.in_proj_bias)
         p = self.dropout if training else 0.0
-        o = Fn.AttentionFn.apply(qkv, None, self.num_heads, causal, window, key_bias, None, None, p, next_seed() if p > 0 else 0)
+        o = Fn.AttentionFn.apply(qkv, None, self.num_heads, causal, window, key_bias, None, None, p, next_seed("attn", p) if p > 0 else 0)
         return Fn.linear(o, self.out_proj.weight, self.out_proj.bias)
 
     def project_kv(self, memory):
@@ -103,7 +103,7 @@ class MultiheadAttention(nn.Module):
         d = self.embed_dim
         q = Fn.linear(x, self.in_proj_weight, self.in_proj_bias, rows=(0, d))
         p = self.dropout if training else 0.0
-        o = Fn.AttentionFn.apply(q, kv, self.num_heads, False, -1, key_bias, blk_lq, blk_lkv, p, next_seed() if p > 0 else 0)
+        o = Fn.AttentionFn.apply(q, kv, self.num_heads, False, -1, key_bias, blk_lq, blk_lkv, p, next_seed("attn", p) if p > 0 else 0)
         return Fn.linear(o, self.out_proj.weight, self.out_proj.bias)
 
 
@@ -122,7 +122,7 @@ class TransformerDecoderLayer(nn.Module):
     def forward(self, x, memory, window: int, self_key_bias, mem_key_bias, kv=None):
         """kv: this layer's cross-attention K|V of `memory` when the decoder projected all layers at once."""
         tr, p = self.training, self.dropout_p
-        drop = (lambda: (p, next_seed())) if (tr and p > 0.0) else (lambda: None)      # dropout1/2/3 ride inside the add+LayerNorm kernels
+        drop = (lambda: (p, next_seed("rows", p))) if (tr and p > 0.0) else (lambda: None)      # dropout1/2/3 ride inside the add+LayerNorm kernels
         sa = self.self_attn.self_attention(x, True, window, self_key_bias, tr)
         x = Fn.AddLayerNormFn.apply(sa, x, self.norm1.weight, self.norm1.bias, drop())
         if kv is None:

@@ -53,7 +53,7 @@ class MixDropout(nn.Module):
         p, channel_mode = self.pick()
         if not self.training or p <= 0.0:
             return x, 1.0
-        return Fn.DropoutFn.apply(x, p, next_seed(), channel_mode, fused_bwd), 1.0 / (1.0 - p)
+        return Fn.DropoutFn.apply(x, p, next_seed("nhwc", p, channel_mode), channel_mode, fused_bwd), 1.0 / (1.0 - p)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # logical NCHW in, NCHW out (API parity)
         y, _ = self.apply_nhwc(x.permute(0, 2, 3, 1).contiguous(), False)
@@ -103,7 +103,7 @@ class ConvBlock(nn.Module):
         p, channel_mode = self.dropout.pick()
         if not self.training or p <= 0.0:
             return None
-        return (p, next_seed(), channel_mode)
+        return (p, next_seed("nhwc", p, channel_mode), channel_mode)
 
     def nhwc(self, x: torch.Tensor, in_mask: bool, in_scale: float, defer_out: bool) -> Tuple[torch.Tensor, float]:
         """x NHWC.  in_mask/in_scale: x is a ReLU(+dropout) output whose activation backward this block must

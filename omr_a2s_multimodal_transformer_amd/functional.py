@@ -59,15 +59,16 @@ class Conv3x3Fn(Function):
         cout = weight.shape[0]
         if drop is not None and x.shape[-1] == 1:
             raise RuntimeError("fused dropout is not available on the 1-channel first-layer kernel")
-        ws = torch.zeros((B, cout, 2), dtype=torch.float64, device=x.device) if want_stats else None
+        Ho, Wo = K.conv_out_hw(x.shape[1], x.shape[2], stride)
+        ws, slots = K.conv_stat_ws(B, Ho, Wo, cout, x.device) if want_stats else (None, 0)
         y = K.conv3x3(x, wt(weight, dt), bias.omr_phys, stride=stride, relu=relu, in_stats=in_stats, drop=drop,
-                      stat_mode=1 if want_stats else 0, stat_ws=ws)
+                      stat_mode=1 if want_stats else 0, stat_ws=ws, stat_slots=slots)
         own_scale = 1.0 / (1.0 - drop[0]) if drop is not None else 1.0
         ctx.cfg = (stride, relu, mask_own, mask_input, in_scale, own_scale)
         ctx.weight, ctx.bias, ctx.stats = weight, bias, in_stats
         ctx.save_for_backward(x, y if (relu and mask_own) else None)
         if want_stats:
-            mean, rstd = K.instnorm_finalize(ws, y.shape[1] * y.shape[2])
+            mean, rstd = K.instnorm_finalize(ws, slots, B, cout, Ho * Wo)
             ctx.mark_non_differentiable(mean, rstd)
             return y, mean, rstd
         return y
@@ -89,9 +90,9 @@ class Conv3x3Fn(Function):
                 dx = K.conv3x3(g, wd, None, stride=(1, 1), dil=stride, out_hw=(H, W), out_mask=x if mask_input else None, mask_scale=in_scale)
             else:
                 # data gradient w.r.t. the normalised input, with the InstanceNorm-backward sums reduced in its epilogue
-                ws = torch.zeros((x.shape[0], x.shape[3], 2), dtype=torch.float64, device=x.device)
-                dxh = K.conv3x3(g, wd, None, stride=(1, 1), dil=stride, out_hw=(H, W), stat_mode=2, stat_ws=ws, stat_x=x, stat_stats=stats)
-                dx = K.instnorm_bwd_apply(dxh, x, stats[0], stats[1], ws, relu_mask=mask_input, relu_scale=in_scale)
+                ws, slots = K.conv_stat_ws(x.shape[0], H, W, x.shape[3], x.device)
+                dxh = K.conv3x3(g, wd, None, stride=(1, 1), dil=stride, out_hw=(H, W), stat_mode=2, stat_ws=ws, stat_slots=slots, stat_x=x, stat_stats=stats)
+                dx = K.instnorm_bwd_apply(dxh, x, stats[0], stats[1], ws, slots, relu_mask=mask_input, relu_scale=in_scale)
         return (dx,) + (None,) * 10
 
 

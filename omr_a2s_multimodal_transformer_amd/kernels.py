@@ -166,6 +166,16 @@ def argmax(x: Tensor) -> Tuple[Tensor, Tensor]:
     return idx, val
 
 
+def weighted_argmax(la: Tensor, lb: Tensor, alpha: float) -> Tuple[Tensor, Tensor]:
+    """argmax(alpha * softmax(la) + (1 - alpha) * softmax(lb)) of two fp32 logit rows [n] -> (index int64 [1], probability fp32 [1])."""
+    require_cuda(la, lb)
+    assert la.dtype == lb.dtype == torch.float32 and la.dim() == lb.dim() == 1 and la.numel() == lb.numel() and la.is_contiguous() and lb.is_contiguous()
+    idx = torch.empty(1, dtype=torch.int64, device=la.device)
+    prob = torch.empty(1, dtype=torch.float32, device=la.device)
+    lib().call("omr_weighted_argmax", ptr(la), ptr(lb), la.numel(), float(alpha), ptr(idx), ptr(prob), cur_stream())
+    return idx, prob
+
+
 def topk_logprob(x: Tensor, k: int) -> Tuple[Tensor, Tensor]:
     """x fp32 [rows, n] -> (token ids int64 [rows, k], log-probabilities fp32 [rows, k]), best first."""
     require_cuda(x)
@@ -178,8 +188,16 @@ def topk_logprob(x: Tensor, k: int) -> Tuple[Tensor, Tensor]:
 
 # ------------------------------------------------------------------------------------------------ normalisation
 
-def _in_ws(B: int, C: int, device) -> Tensor:
-    return torch.empty(lib().query("omr_instnorm_workspace_bytes", B, C), dtype=torch.uint8, device=device)
+def _stat_ws(B: int, C: int, slots: int, device, zero: bool) -> Tensor:
+    """fp64 statistics workspace: partial slots [B][slots][C][2] + compact sums [B][C][2] (include/omr_hip.h, normalisation)."""
+    n = lib().query("omr_instnorm_workspace_bytes", B, C, slots) // 8
+    return (torch.zeros if zero else torch.empty)(n, dtype=torch.float64, device=device)
+
+
+def conv_stat_ws(B: int, Ho: int, Wo: int, C: int, device) -> Tuple[Tensor, int]:
+    """Zeroed workspace + slot count for a conv launch with a fused statistics epilogue (stat_mode 1 / 2)."""
+    slots = lib().query("omr_conv3x3_stat_slots", B, Ho, Wo)
+    return _stat_ws(B, C, slots, device, True), slots
 
 
 def instnorm_stats(x: Tensor, eps: float = 1e-3) -> Tuple[Tensor, Tensor]:
@@ -189,28 +207,28 @@ def instnorm_stats(x: Tensor, eps: float = 1e-3) -> Tuple[Tensor, Tensor]:
     assert x.is_contiguous()
     mean = torch.empty((B, C), dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
-    lib().call("omr_instnorm_stats", dtype_code(x.dtype), ptr(x), ptr(mean), ptr(rstd), B, H * W, C, eps, ptr(_in_ws(B, C, x.device)), cur_stream())
+    ws = _stat_ws(B, C, lib().query("omr_instnorm_slots", B, H * W), x.device, False)
+    lib().call("omr_instnorm_stats", dtype_code(x.dtype), ptr(x), ptr(mean), ptr(rstd), B, H * W, C, eps, ptr(ws), cur_stream())
     return mean, rstd
 
 
-def instnorm_finalize(ws: Tensor, HW: int, eps: float = 1e-3) -> Tuple[Tensor, Tensor]:
-    """fp64 {sum, sum of squares} [B,C,2] -> (mean, rstd) fp32 [B,C]."""
+def instnorm_finalize(ws: Tensor, slots: int, B: int, C: int, HW: int, eps: float = 1e-3) -> Tuple[Tensor, Tensor]:
+    """fp64 {sum, sum of squares} slots (conv_stat_ws layout) -> (mean, rstd) fp32 [B,C]."""
     require_cuda(ws)
-    B, C, _ = ws.shape
     mean = torch.empty((B, C), dtype=torch.float32, device=ws.device)
     rstd = torch.empty_like(mean)
-    lib().call("omr_instnorm_finalize", ptr(ws), ptr(mean), ptr(rstd), B, HW, C, eps, cur_stream())
+    lib().call("omr_instnorm_finalize", ptr(ws), slots, ptr(mean), ptr(rstd), B, HW, C, eps, cur_stream())
     return mean, rstd
 
 
-def instnorm_bwd_apply(dxhat: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, ws: Tensor, relu_mask: bool, relu_scale: float = 1.0) -> Tensor:
-    """InstanceNorm backward apply step with the {sum g, sum g*xhat} sums already in ws (fp64 [B,C,2])."""
+def instnorm_bwd_apply(dxhat: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, ws: Tensor, slots: int, relu_mask: bool, relu_scale: float = 1.0) -> Tensor:
+    """InstanceNorm backward apply step with the {sum g, sum g*xhat} sums already in the slots of ws (conv_stat_ws layout)."""
     require_cuda(dxhat, x, ws)
     B, H, W, C = x.shape
     assert dxhat.shape == x.shape and dxhat.is_contiguous() and x.is_contiguous() and ws.dtype == torch.float64
     dx = torch.empty_like(x)
     lib().call("omr_instnorm_bwd_apply", dtype_code(x.dtype), ptr(dxhat), ptr(x), ptr(mean), ptr(rstd), ptr(dx), B, H * W, C, int(relu_mask),
-               float(relu_scale), ptr(ws), cur_stream())
+               float(relu_scale), ptr(ws), slots, cur_stream())
     return dx
 
 
@@ -219,8 +237,9 @@ def instnorm_bwd(dxhat: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, relu_mask
     B, H, W, C = x.shape
     assert dxhat.shape == x.shape and dxhat.is_contiguous() and x.is_contiguous()
     dx = torch.empty_like(x)
+    ws = _stat_ws(B, C, lib().query("omr_instnorm_slots", B, H * W), x.device, False)
     lib().call("omr_instnorm_bwd", dtype_code(x.dtype), ptr(dxhat), ptr(x), ptr(mean), ptr(rstd), ptr(dx), B, H * W, C, int(relu_mask),
-               float(relu_scale), ptr(_in_ws(B, C, x.device)), cur_stream())
+               float(relu_scale), ptr(ws), cur_stream())
     return dx
 
 
@@ -262,10 +281,10 @@ def conv_out_hw(H: int, W: int, stride: Tuple[int, int]) -> Tuple[int, int]:
 
 def conv3x3(x: Tensor, w_phys: Tensor, bias: Optional[Tensor], stride=(1, 1), relu: bool = False, in_stats=None, out_mask: Optional[Tensor] = None,
             mask_scale: float = 1.0, dil=(1, 1), out_hw: Optional[Tuple[int, int]] = None, drop=None, stat_mode: int = 0,
-            stat_ws: Optional[Tensor] = None, stat_x: Optional[Tensor] = None, stat_stats=None) -> Tensor:
+            stat_ws: Optional[Tensor] = None, stat_slots: int = 0, stat_x: Optional[Tensor] = None, stat_stats=None) -> Tensor:
     """x NHWC [B,H,W,CIN]; w_phys [COUT,3,3,CIN] contiguous; returns NHWC [B,Ho,Wo,COUT].
     drop = (p, seed, channel_mode): fused dropout after the ReLU.  stat_mode 1/2: fused per-(image, channel) reductions of
-    the stored output into the fp64 buffer stat_ws [B,COUT,2] (see include/omr_hip.h)."""
+    the stored output into the fp64 slot workspace (stat_ws, stat_slots) = conv_stat_ws(...) (see include/omr_hip.h)."""
     require_cuda(x, w_phys, bias, out_mask, stat_ws, stat_x)
     B, H, W, CIN = x.shape
     COUT = w_phys.shape[0]
@@ -285,13 +304,13 @@ def conv3x3(x: Tensor, w_phys: Tensor, bias: Optional[Tensor], stride=(1, 1), re
     p, seed, chan = drop if drop is not None else (0.0, 0, False)
     smean = srstd = None
     if stat_mode:
-        assert stat_ws is not None and stat_ws.dtype == torch.float64 and tuple(stat_ws.shape) == (B, COUT, 2) and stat_ws.is_contiguous()
+        assert stat_ws is not None and stat_ws.dtype == torch.float64 and stat_slots >= 1 and stat_ws.numel() >= B * stat_slots * COUT * 2
     if stat_mode == 2:
         smean, srstd = stat_stats
         assert stat_x is not None and stat_x.shape == y.shape and stat_x.is_contiguous() and tuple(smean.shape) == (B, COUT)
     lib().call("omr_conv3x3_fwd", dtype_code(x.dtype), ptr(x), ptr(w_phys), ptr(bias), ptr(y), ptr(mean), ptr(rstd), ptr(out_mask), float(mask_scale),
                B, H, W, CIN, COUT, stride[0], stride[1], dil[0], dil[1], Ho, Wo, int(relu), float(p), int(seed) & (2**64 - 1), int(chan),
-               int(stat_mode), ptr(stat_ws), ptr(stat_x), ptr(smean), ptr(srstd), cur_stream())
+               int(stat_mode), ptr(stat_ws), int(stat_slots), ptr(stat_x), ptr(smean), ptr(srstd), cur_stream())
     return y
 
 
@@ -384,6 +403,13 @@ def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, nhead: int, *, causal=False, win
     lib().call("omr_attn_bwd", dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ldq, ldk,
                ldv, ldo, lddo, lddq, lddk, lddv, bsq, bsk, bsv, bso, bsdo, bsdq, bsdk, bsdv, B, nhead, T, S, hd, int(causal), int(window),
                ptr(key_bias), ptr(blk_lq), ptr(blk_lkv), float(dropout_p), int(seed) & (2**64 - 1), cur_stream())
+
+
+def attn_dropout_mask(B: int, H: int, T: int, S: int, p: float, seed: int, device) -> Tensor:
+    """uint8 [B,H,T,S] keep-mask of the attention-probability dropout for (p, seed): test / debug entry."""
+    out = torch.empty((B, H, T, S), dtype=torch.uint8, device=device)
+    lib().call("omr_attn_dropout_mask", ptr(out), B, H, T, S, float(p), int(seed) & (2**64 - 1), cur_stream())
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ loss

@@ -59,34 +59,63 @@ class LightningModule(nn.Module):
 
 
 class Trainer:
-    """fit/test loops with the hook order Lightning uses for the reference's modules (single process per GPU;
-    data-parallel gradient averaging is attached through ddp.GradReducer)."""
+    """fit/test loops with the hook order Lightning uses for the reference's modules.  One process per GPU: when
+    torch.distributed is initialised with more than one rank, fit() attaches the model's gradient reducer (ddp.GradReducer:
+    rank-0 parameter broadcast, bucketed all-reduce overlapped with backward), steps the optimizer on the MEAN gradient
+    (Lightning-DDP semantics) and the evaluation loops shard their samples over the ranks and all-reduce the metric counts."""
 
     def __init__(self, max_epochs: int = 1, check_val_every_n_epoch: int = 1, reducer=None, log_every: int = 0, **_ignored):
         self.max_epochs, self.check_val_every_n_epoch, self.reducer, self.log_every = max_epochs, check_val_every_n_epoch, reducer, log_every
         self.callback_metrics: Dict[str, Any] = {}
 
+    @staticmethod
+    def _world() -> int:
+        import torch.distributed as dist
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    @staticmethod
+    def _rank() -> int:
+        import torch.distributed as dist
+        return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+    def _reducer_for(self, model):
+        if self.reducer is None and self._world() > 1:
+            self.reducer = getattr(model, "_reducer", None) or model.attach_reducer()
+        return self.reducer
+
     def fit(self, model, train_dataloaders: Iterable, val_dataloaders: Optional[Iterable] = None) -> None:
         opt = model.configure_optimizers()
+        reducer = self._reducer_for(model)
         for epoch in range(self.max_epochs):
             model.train()
+            if hasattr(train_dataloaders, "set_epoch"):
+                train_dataloaders.set_epoch(epoch)          # ddp.ShardedLoader: DistributedSampler semantics
             for i, batch in enumerate(train_dataloaders):
                 batch = _to_device(batch, model.device)
                 opt.zero_grad()
                 loss = model.training_step(batch, i)
                 loss.backward()
-                if self.reducer is not None:
-                    self.reducer.finish()
-                opt.step()
+                if reducer is not None:
+                    reducer.finish()
+                    opt.step(grad_scale=reducer.grad_scale)      # all-reduced SUM -> mean (1/world folded into the Adam kernel)
+                else:
+                    opt.step()
                 if self.log_every and i % self.log_every == 0:
                     print(f"epoch {epoch} step {i} train_loss {float(loss):.4f}")
             if val_dataloaders is not None and (epoch + 1) % self.check_val_every_n_epoch == 0:
                 self.callback_metrics.update(self._eval(model, val_dataloaders, "val"))
 
     def _eval(self, model, loader: Iterable, name: str) -> Dict[str, float]:
+        """Validation / test loop (bs = 1 samples, model.py:170-218).  Data parallel: rank r decodes samples r, r + world, ...;
+        on_validation_epoch_end all-reduces the edit-distance counts, so every rank returns the single-process metrics."""
         model.eval()
+        world, rank = self._world(), self._rank()
+        if world > 1:
+            self._reducer_for(model)
         with torch.no_grad():
             for i, batch in enumerate(loader):
+                if i % world != rank:
+                    continue
                 model.validation_step(_to_device(batch, model.device), i)
             metrics = model.on_validation_epoch_end(name=name)
         return {f"{name}_{k}": v for k, v in metrics.items()}
@@ -98,8 +127,11 @@ class Trainer:
 
 
 def _to_device(batch, device):
+    """Float inputs go to the device (non-blocking); integer tensors (tokens, lengths) stay on the host: the token-noise step
+    is host logic (model.py:152-160) and the modules upload what the kernels need with pinned, non-blocking copies -- moving
+    y_in to the GPU here would force a blocking D2H read (a full stream drain) in every training step."""
     if isinstance(batch, torch.Tensor):
-        return batch.to(device, non_blocking=True)
+        return batch.to(device, non_blocking=True) if batch.is_floating_point() else batch
     if isinstance(batch, (list, tuple)):
         return type(batch)(_to_device(b, device) for b in batch)
     return batch

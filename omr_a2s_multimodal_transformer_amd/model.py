@@ -17,7 +17,7 @@ from .config import ModelConfig
 from .decoder import Decoder, MultiheadAttention
 from .encoder import HEIGHT_REDUCTION, WIDTH_REDUCTION, Encoder
 from .lightning_shim import LightningModule
-from .metrics import compute_metrics
+from .metrics import compute_metrics, compute_metrics_sharded
 from .runtime import FlatModuleMixin
 from .synthetic import EOS_TOKEN, SOS_TOKEN
 
@@ -57,7 +57,7 @@ class PositionalEncoding2D(nn.Module):
         y = Fn.AddPE2DFn.apply(xn, self.pe_hwc)
         if self.training and self.dropout_p > 0:
             from .runtime import next_seed
-            y = Fn.DropoutFn.apply(y, self.dropout_p, next_seed(), False, False)
+            y = Fn.DropoutFn.apply(y, self.dropout_p, next_seed("nhwc", self.dropout_p), False, False)
         return y.permute(0, 3, 1, 2)
 
 
@@ -122,6 +122,7 @@ class _Base(FlatModuleMixin, LightningModule):
         dec_names = [n for n in flat.names if n not in set(enc_names)]
         buckets = [flat.slice_of(enc_names), flat.slice_of(dec_names)]
         self._reducer = GradReducer(flat, process_group, buckets)
+        self._reducer.broadcast_state()        # replicas start from rank 0's parameters (and Adam moments), like Lightning's DDP wrapper
         return self._reducer
 
     def _boundary(self, *mems: torch.Tensor):
@@ -262,7 +263,8 @@ class _Base(FlatModuleMixin, LightningModule):
 
     @torch.no_grad()
     def on_validation_epoch_end(self, name: str = "val", print_random_samples: bool = False) -> Dict[str, float]:
-        metrics = compute_metrics(y_true=self.Y, y_pred=self.YHat)
+        # data-parallel evaluation: each rank decoded its shard; the edit-distance counts are all-reduced (metrics.py)
+        metrics = compute_metrics_sharded(self.Y, self.YHat) if self._reducer is not None else compute_metrics(y_true=self.Y, y_pred=self.YHat)
         for k, v in metrics.items():
             self.log(f"{name}_{k}", v, prog_bar=True, logger=True, on_epoch=True)
         if print_random_samples:
@@ -311,14 +313,13 @@ class Transformer(_Base):
     def apply_teacher_forcing(self, y: torch.Tensor) -> torch.Tensor:
         """model.py:152-160: each non-pad token is replaced w.p. teacher_forcing_prob by randint(0, V-1) drawn
         from Python's `random` in row-major order (same draw sequence as the reference's double loop)."""
-        yc = y.detach().cpu()
-        out = yc.clone()
-        V = len(self.w2i)
-        for i in range(yc.size(0)):
-            row = yc[i].tolist()
+        rows = y.detach().cpu().tolist()            # plain Python lists: no tensor indexing inside the B x T loop
+        V, p, pad, rnd, rint = len(self.w2i), self.teacher_forcing_prob, self.padding_idx, random.random, random.randint
+        for row in rows:
             for j, tok in enumerate(row):
-                if random.random() < self.teacher_forcing_prob and tok != self.padding_idx:
-                    out[i, j] = random.randint(0, V - 1)
+                if rnd() < p and tok != pad:        # same short-circuit as the reference: randint is drawn only for replaced tokens
+                    row[j] = rint(0, V - 1)
+        out = torch.tensor(rows, dtype=y.dtype)
         return out.pin_memory() if (not y.is_cuda and torch.cuda.is_available()) else out.to(y.device)
 
     def training_step(self, batch, batch_idx) -> torch.Tensor:
@@ -407,11 +408,14 @@ class MultimodalTransformer(_Base):
         xi = self._encode(self.image_encoder, self.image_pos_2d, xi)
         xa = self._encode(self.audio_encoder, self.audio_pos_2d, xa)
         xi, xa = self._boundary(xi, xa)
+        self._touched = None           # which sub-modules get gradients this step: the optimizer skips the others (FusedAdam)
         if apply_teacher_forcing_modality:
             modality = self.apply_teacher_forcing_modality()
             if modality == "image":
+                self._touched = ("image_encoder", "decoder")
                 return xi, xli
             elif modality == "audio":
+                self._touched = ("audio_encoder", "decoder")
                 return xa, xla
             elif modality == "both":
                 x, xl = self.mixer(xi=xi, xa=xa, xli=xli, xla=xla)

@@ -114,35 +114,75 @@ class FlatParams:
         e = max((o + c + ALIGN - 1) // ALIGN * ALIGN for o, c in offs)
         return b, e
 
+    def module_ranges(self) -> "Dict[str, Tuple[int, int]]":
+        """{top-level sub-module name: [begin, end)}: the contiguous range of the flat buffers each top-level sub-module
+        (encoder, image_encoder, audio_encoder, decoder, cross_attn) owns.  Placement keeps every sub-module contiguous (the
+        grouped cross-attention in_proj family lies inside `decoder`); checked here."""
+        groups: Dict[str, List[str]] = {}
+        for n in self.names:
+            groups.setdefault(n.split(".", 1)[0], []).append(n)
+        ranges = {g: self.slice_of(ns) for g, ns in groups.items()}
+        spans = sorted(ranges.values())
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), "top-level sub-modules overlap in the flat buffer"
+        return ranges
+
 
 class FusedAdam:
-    """torch.optim.Adam(lr=1e-4, amsgrad=False) semantics (model.py:134-139,475-483) as one kernel over the
-    flat buffers.  Interface subset of torch.optim.Optimizer: step / zero_grad / param_groups / state_dict."""
+    """torch.optim.Adam(lr=1e-4, amsgrad=False) semantics (model.py:134-139,475-483) as one kernel launch per top-level
+    sub-module over the flat buffers (one launch in the common case that every sub-module has gradients).
+    Interface subset of torch.optim.Optimizer: step / zero_grad / param_groups / state_dict.
 
-    def __init__(self, flat: FlatParams, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8):
+    Parameters WITHOUT a gradient are skipped like torch.optim.Adam skips `p.grad is None` (Lightning zeroes with
+    set_to_none): no update from stale momentum, no moment decay, no step count.  In MultimodalTransformer the modality-drop
+    steps (model.py:510-519) leave one encoder and cross_attn without gradients; the model reports the sub-modules that took
+    part in the step through `touched_fn` and each sub-module keeps its own step count for the bias correction.  (Under data
+    parallelism every rank takes the same branch -- same Python `random` stream -- so all ranks skip the same slices.)"""
+
+    def __init__(self, flat: FlatParams, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, touched_fn=None):
         self.flat = flat
         self.param_groups = [dict(params=flat.params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)]
-        self.step_count = 0
+        self.ranges = flat.module_ranges()
+        self.steps = {g: 0 for g in self.ranges}
+        self.touched_fn = touched_fn
         if flat.exp_avg is None:
             flat.exp_avg = torch.zeros_like(flat.master)
             flat.exp_avg_sq = torch.zeros_like(flat.master)
 
+    @property
+    def step_count(self) -> int:
+        return max(self.steps.values())
+
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.flat.zero_grad()
 
-    def step(self, grad_scale: float = 1.0) -> None:
+    def step(self, grad_scale: float = 1.0, touched=None) -> None:
+        """touched: names of the top-level sub-modules that received gradients this step (None = all; default: ask the model)."""
         g = self.param_groups[0]
-        self.step_count += 1
         f = self.flat
+        if touched is None and self.touched_fn is not None:
+            touched = self.touched_fn()
+        names = list(self.ranges) if touched is None else [n for n in self.ranges if n in set(touched)]
+        for n in names:
+            self.steps[n] += 1
         from .runtime import WgradStream
         WgradStream.join()
-        K.adam_step(f.master, f.grad, f.exp_avg, f.exp_avg_sq, self.step_count, g["lr"], g["betas"], g["eps"], grad_scale, p_lowp=f.lowp)
+        # merge neighbouring ranges that share a step count: one launch over the whole buffer in the common case
+        runs: List[List[int]] = []
+        for n in sorted(names, key=lambda k: self.ranges[k][0]):
+            b, e = self.ranges[n]
+            if runs and runs[-1][1] == b and runs[-1][2] == self.steps[n]:
+                runs[-1][1] = e
+            else:
+                runs.append([b, e, self.steps[n]])
+        for b, e, st in runs:
+            K.adam_step(f.master[b:e], f.grad[b:e], f.exp_avg[b:e], f.exp_avg_sq[b:e], st, g["lr"], g["betas"], g["eps"], grad_scale,
+                        p_lowp=None if f.lowp is None else f.lowp[b:e])
 
     def state_dict(self):
-        return dict(step=self.step_count, exp_avg=self.flat.exp_avg, exp_avg_sq=self.flat.exp_avg_sq, param_groups=[
+        return dict(step=self.step_count, steps=dict(self.steps), exp_avg=self.flat.exp_avg, exp_avg_sq=self.flat.exp_avg_sq, param_groups=[
             {k: v for k, v in self.param_groups[0].items() if k != "params"}])
 
     def load_state_dict(self, sd) -> None:
-        self.step_count = int(sd["step"])
+        self.steps = {g: int(sd.get("steps", {}).get(g, sd["step"])) for g in self.ranges}
         self.flat.exp_avg.copy_(sd["exp_avg"])
         self.flat.exp_avg_sq.copy_(sd["exp_avg_sq"])

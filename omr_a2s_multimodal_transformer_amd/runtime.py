@@ -20,8 +20,33 @@ def seed_dropout(seed: int, rank: int = 0) -> None:
     _seed_stream.seed(seed * 1000003 + rank)
 
 
-def next_seed() -> int:
-    return _seed_stream.getrandbits(63)
+_trace = None      # list of (kind, p, seed, channel_mode) while a dropout trace is being recorded
+
+
+def next_seed(kind: str = "", p: float = 0.0, channel_mode: bool = False) -> int:
+    """Seed of the next dropout site.  `kind` names the site's mask convention for the trace: "nhwc" (MixDropout /
+    PositionalEncoding2D on NHWC maps; channel_mode = nn.Dropout2d), "rows" (elementwise over a row-major [rows, d] tensor:
+    PE1D, dropout1/2/3, FFN) or "attn" (attention probabilities, omr_attn_dropout_mask)."""
+    seed = _seed_stream.getrandbits(63)
+    if _trace is not None:
+        _trace.append((kind, float(p), seed, bool(channel_mode)))
+    return seed
+
+
+class trace_dropout:
+    """Context manager that records every dropout site of the forward passes run inside it, in call order.  The masks are
+    pure functions of (seed, element index), so a checker can materialise each site's mask afterwards (omr_dropout on a
+    tensor of ones, omr_attn_dropout_mask) and inject it into the CPU oracle (tests/test_dropout_parity_gpu.py)."""
+
+    def __enter__(self):
+        global _trace
+        self.prev, _trace = _trace, []
+        return _trace
+
+    def __exit__(self, *exc):
+        global _trace
+        _trace = self.prev
+        return False
 
 
 class WgradStream:
@@ -107,8 +132,10 @@ class FlatModuleMixin:
         else:
             nn.Module.zero_grad(self, set_to_none)
 
+    _touched = None     # top-level sub-modules whose parameters took part in the last forward (None = all); see FusedAdam
+
     def make_optimizer(self, lr: float = 1e-4) -> FusedAdam:
-        return FusedAdam(self.ensure_flat(), lr=lr)
+        return FusedAdam(self.ensure_flat(), lr=lr, touched_fn=lambda: self._touched)
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):  # type: ignore[override]
         out = nn.Module.load_state_dict(self, state_dict, strict=strict)

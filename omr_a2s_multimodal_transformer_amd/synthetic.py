@@ -174,3 +174,18 @@ def synthetic_unimodal_batch(batch: int, height: int, width: int, seq_len: int, 
         y_in[i, :ti] = y[:-1]
         y_out[i, :ti] = y[1:]
     return x, xl, y_in, y_out
+
+
+def seeded_dropout_mask(seed: int, site: int, p: float, shape: Tuple[int, ...], channel: bool = False) -> torch.Tensor:
+    """Multiplicative dropout mask keep / (1 - p) for the site-th dropout call of a forward pass, a pure function of
+    (seed, site): the golden generator injects it into the reference's nn.Dropout / nn.Dropout2d / attention dropout
+    (tests/golden/gen_golden_r2.py) and the oracle tests inject the same mask into oracle.ref_cpu.DropPlan.
+    channel=True: one decision per (b, c) of a [B, C, ...] tensor (nn.Dropout2d).  The random numbers are drawn over the
+    flat element count, so [B*H, T, S] and [B, H, T, S] views of attention probabilities get the same mask."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed * 7919 + site)
+    if channel:
+        shape = tuple(shape[:2]) + (1,) * (len(shape) - 2)
+    n = int(math.prod(shape))
+    keep = torch.rand(n, generator=g, dtype=torch.float32) >= p
+    return keep.to(torch.float32).view(shape) / (1.0 - p)

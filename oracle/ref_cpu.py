@@ -11,12 +11,17 @@ reference's own modules imported in the build container by ``tests/golden/gen_go
 (see ``tests/test_oracle_golden.py``).
 
 Every function cites the reference lines it restates (paths relative to the reference
-root).  All dropout layers are identity here (eval-mode / p=0 parity, SURVEY.md section 7
-"Parity under dropout").
+root).  Dropout layers are identity by default (eval-mode / p=0 parity); with a ``DropPlan``
+the functions reproduce the reference's TRAIN-mode forward -- every nn.Dropout / nn.Dropout2d /
+attention-probability dropout site in the reference's call order, with the Python ``random`` draws
+that choose the dropout position and kind (encoder.py:102,160,219) -- taking each site's mask from the
+plan instead of torch's RNG.  That form is pinned by tests/golden/f12_dropout.npz (the reference's own
+modules run with the same injected masks) and is what checks the HIP path's counter-based masks.
 """
 from __future__ import annotations
 
 import math
+import random
 
 import numpy as np
 from dataclasses import dataclass
@@ -42,6 +47,41 @@ class OracleCfg:
     num_layers: int = 8
     attn_window: int = -1
     pad_idx: int = 0
+    dropout: float = 0.1  # decoder.py:65, model.py:29,289 (used only with a DropPlan)
+    encoder_dropout: float = 0.5  # encoder.py:251
+
+
+class DropPlan:
+    """Train-mode dropout with injected masks.  ``mask_fn(site, kind, p, shape, channel)`` returns the multiplicative mask
+    (keep / (1 - p), broadcastable to ``shape``) of the site-th dropout call of the forward, in the reference's call order.
+    kind: "nhwc" = a [B,C,H,W] feature map (MixDropout, PositionalEncoding2D; channel=True is nn.Dropout2d: one decision
+    per (b, c)), "rows" = a [B,T,d] token tensor, "attn" = attention probabilities [B,nhead,T,S].  Sites with p = 0 are
+    identities and do not count."""
+
+    def __init__(self, mask_fn):
+        self.mask_fn = mask_fn
+        self.sites = 0
+
+    def apply(self, x: Tensor, kind: str, p: float, channel: bool = False) -> Tensor:
+        if p <= 0.0:
+            return x
+        m = self.mask_fn(self.sites, kind, float(p), tuple(x.shape), channel)
+        self.sites += 1
+        return x * m
+
+
+def _drop(drop: Optional[DropPlan], x: Tensor, kind: str, p: float) -> Tensor:
+    return x if drop is None else drop.apply(x, kind, p)
+
+
+def mix_dropout(drop: Optional[DropPlan], x: Tensor, p: float) -> Tensor:
+    """MixDropout.forward, encoder.py:101-104: random.random() < 0.5 -> nn.Dropout(p) else nn.Dropout2d(p / 2)
+    (encoder.py:157,216 build it as MixDropout(dropout, dropout / 2))."""
+    if drop is None:
+        return x
+    if random.random() < 0.5:
+        return drop.apply(x, "nhwc", p, channel=False)
+    return drop.apply(x, "nhwc", p / 2, channel=True)
 
 
 # --------------------------------------------------------------------------------------
@@ -59,12 +99,20 @@ def instance_norm(x: Tensor, eps: float = 1e-3) -> Tensor:
     return (x - mean) / torch.sqrt(var + eps)
 
 
-def conv_block(sd: SD, p: str, x: Tensor, stride: Tuple[int, int]) -> Tensor:
-    """ConvBlock.forward, encoder.py:159-181 (dropout = identity)."""
+def conv_block(sd: SD, p: str, x: Tensor, stride: Tuple[int, int], drop: Optional[DropPlan] = None, dp: float = 0.5) -> Tensor:
+    """ConvBlock.forward, encoder.py:159-181.  With a DropPlan: pos = random.randint(1, 3) picks the conv after whose
+    ReLU the MixDropout is applied (encoder.py:160-179)."""
+    pos = random.randint(1, 3) if drop is not None else 0
     x = F.relu(F.conv2d(x, sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1))
+    if pos == 1:
+        x = mix_dropout(drop, x, dp)
     x = F.relu(F.conv2d(x, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1))
+    if pos == 2:
+        x = mix_dropout(drop, x, dp)
     x = instance_norm(x)
     x = F.relu(F.conv2d(x, sd[p + "conv3.weight"], sd[p + "conv3.bias"], padding=1, stride=stride))
+    if pos == 3:
+        x = mix_dropout(drop, x, dp)
     return x
 
 
@@ -75,20 +123,28 @@ def depth_sep_conv(sd: SD, p: str, x: Tensor) -> Tensor:
     return F.conv2d(x, sd[p + "point_conv.weight"], sd[p + "point_conv.bias"])
 
 
-def dsc_block(sd: SD, p: str, x: Tensor) -> Tensor:
+def dsc_block(sd: SD, p: str, x: Tensor, drop: Optional[DropPlan] = None, dp: float = 0.5) -> Tensor:
     """DSCBlock.forward, encoder.py:218-238 (no ReLU after conv3; all strides (1,1) :264-267)."""
+    pos = random.randint(1, 3) if drop is not None else 0
     x = F.relu(depth_sep_conv(sd, p + "conv1.", x))
+    if pos == 1:
+        x = mix_dropout(drop, x, dp)
     x = F.relu(depth_sep_conv(sd, p + "conv2.", x))
+    if pos == 2:
+        x = mix_dropout(drop, x, dp)
     x = instance_norm(x)
-    return depth_sep_conv(sd, p + "conv3.", x)
+    x = depth_sep_conv(sd, p + "conv3.", x)
+    if pos == 3:
+        x = mix_dropout(drop, x, dp)
+    return x
 
 
-def encoder(sd: SD, p: str, x: Tensor) -> Tensor:
+def encoder(sd: SD, p: str, x: Tensor, drop: Optional[DropPlan] = None, dp: float = 0.5) -> Tensor:
     """Encoder.forward, encoder.py:271-291. x [B,1,H,W] -> [B,C,ceil(H/16),ceil(W/8)]."""
     for i, s in enumerate(CONV_STRIDES):
-        x = conv_block(sd, f"{p}conv_blocks.{i}.", x, s)
+        x = conv_block(sd, f"{p}conv_blocks.{i}.", x, s, drop, dp)
     for i in range(4):
-        xt = dsc_block(sd, f"{p}dscblocks.{i}.", x)
+        xt = dsc_block(sd, f"{p}dscblocks.{i}.", x, drop, dp)
         x = x + xt if x.shape == xt.shape else xt  # encoder.py:289
     return x
 
@@ -122,10 +178,13 @@ def pe1d_table(max_len: int, emb_dim: int) -> Tensor:
     return pe
 
 
-def encode_to_memory(sd: SD, enc_prefix: str, pe: Tensor, x: Tensor) -> Tensor:
-    """encoder -> +PE2D -> flatten(2).permute(0,2,1), model.py:143-147. -> [B,S,C]."""
-    f = encoder(sd, enc_prefix, x)
+def encode_to_memory(sd: SD, enc_prefix: str, pe: Tensor, x: Tensor, drop: Optional[DropPlan] = None,
+                     cfg: Optional["OracleCfg"] = None) -> Tensor:
+    """encoder -> +PE2D (-> Dropout(0.1), model.py:31,48) -> flatten(2).permute(0,2,1), model.py:143-147. -> [B,S,C]."""
+    cfg = cfg if cfg is not None else OracleCfg()
+    f = encoder(sd, enc_prefix, x, drop, cfg.encoder_dropout)
     f = f + pe[:, :, : f.shape[2], : f.shape[3]]
+    f = _drop(drop, f, "nhwc", cfg.dropout)
     return f.flatten(2).permute(0, 2, 1).contiguous()
 
 
@@ -143,11 +202,14 @@ def mha(
     out_b: Tensor,
     nhead: int,
     score_bias: Optional[Tensor] = None,
+    drop: Optional[DropPlan] = None,
+    dropout_p: float = 0.0,
 ) -> Tensor:
     """softmax(Q K^T / sqrt(hd) + bias) V with packed in_proj (rows [0:d]=Wq,[d:2d]=Wk,[2d:3d]=Wv),
     heads = contiguous hd-wide channel slices, then out_proj (SURVEY.md Appendix A "MHA math").
     ``score_bias`` broadcasts to [B, nhead, T, S]; float values are ADDED (so a 0/1 float
-    padding mask adds +1.0 -- reference quirk 1), -inf entries mask."""
+    padding mask adds +1.0 -- reference quirk 1), -inf entries mask.  Train mode: dropout on the
+    probabilities (nn.MultiheadAttention dropout, decoder.py:91, model.py:292-297)."""
     b, t, d = q_in.shape
     s = kv_in.shape[1]
     hd = d // nhead
@@ -158,6 +220,7 @@ def mha(
     if score_bias is not None:
         scores = scores + score_bias
     p = torch.softmax(scores, dim=-1)
+    p = _drop(drop, p, "attn", dropout_p)
     o = torch.matmul(p, v).transpose(1, 2).reshape(b, t, d)
     return F.linear(o, out_w, out_b)
 
@@ -204,25 +267,28 @@ def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
     return (x - mu) / torch.sqrt(var + eps) * w + b
 
 
-def decoder_layer(sd: SD, p: str, x: Tensor, memory: Tensor, self_bias: Tensor, mem_bias: Optional[Tensor], nhead: int) -> Tensor:
+def decoder_layer(sd: SD, p: str, x: Tensor, memory: Tensor, self_bias: Tensor, mem_bias: Optional[Tensor], nhead: int,
+                  drop: Optional[DropPlan] = None, dp: float = 0.0) -> Tensor:
     """Post-norm nn.TransformerDecoderLayer (relu, batch_first) as configured at decoder.py:86-95;
-    math per torch nn/modules/transformer.py:1129-1199."""
+    math per torch nn/modules/transformer.py:1129-1199.  Train-mode dropout sites in call order: self-attention
+    probabilities, dropout1, cross-attention probabilities, dropout2, the FFN's inner dropout, dropout3."""
     sa = mha(x, x, sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"],
-             sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"], nhead, self_bias)
-    x = layer_norm(x + sa, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+             sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"], nhead, self_bias, drop, dp)
+    x = layer_norm(x + _drop(drop, sa, "rows", dp), sd[p + "norm1.weight"], sd[p + "norm1.bias"])
     ca = mha(x, memory, sd[p + "multihead_attn.in_proj_weight"], sd[p + "multihead_attn.in_proj_bias"],
-             sd[p + "multihead_attn.out_proj.weight"], sd[p + "multihead_attn.out_proj.bias"], nhead, mem_bias)
-    x = layer_norm(x + ca, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
-    ff = F.linear(F.relu(F.linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"])),
-                  sd[p + "linear2.weight"], sd[p + "linear2.bias"])
-    return layer_norm(x + ff, sd[p + "norm3.weight"], sd[p + "norm3.bias"])
+             sd[p + "multihead_attn.out_proj.weight"], sd[p + "multihead_attn.out_proj.bias"], nhead, mem_bias, drop, dp)
+    x = layer_norm(x + _drop(drop, ca, "rows", dp), sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+    h = _drop(drop, F.relu(F.linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"])), "rows", dp)
+    ff = F.linear(h, sd[p + "linear2.weight"], sd[p + "linear2.bias"])
+    return layer_norm(x + _drop(drop, ff, "rows", dp), sd[p + "norm3.weight"], sd[p + "norm3.bias"])
 
 
-def decoder(sd: SD, p: str, tgt: Tensor, memory: Tensor, memory_len, cfg: OracleCfg) -> Tensor:
+def decoder(sd: SD, p: str, tgt: Tensor, memory: Tensor, memory_len, cfg: OracleCfg, drop: Optional[DropPlan] = None) -> Tensor:
     """Decoder.forward, decoder.py:104-148 -> logits [B, V, T]."""
     b, t = tgt.shape
     emb = sd[p + "embedding.weight"][tgt]  # row pad_idx is zero (nn.Embedding padding_idx)
     x = emb + pe1d_table(t, cfg.d_model)  # decoder.py:124 (no sqrt(d) scaling)
+    x = _drop(drop, x, "rows", cfg.dropout)  # PositionalEncoding1D dropout, decoder.py:19,32
     mem_bias = memory_key_bias(memory, memory_len)
     self_bias = tgt_attn_mask(t, cfg.attn_window).view(1, 1, t, t)
     if mem_bias is not None:
@@ -231,7 +297,7 @@ def decoder(sd: SD, p: str, tgt: Tensor, memory: Tensor, memory_len, cfg: Oracle
         self_bias = self_bias + (tgt == cfg.pad_idx).to(torch.float32).view(b, 1, 1, t)
         mem_bias = mem_bias.view(b, 1, 1, -1)
     for i in range(cfg.num_layers):
-        x = decoder_layer(sd, f"{p}transformer_decoder.layers.{i}.", x, memory, self_bias, mem_bias, cfg.nhead)
+        x = decoder_layer(sd, f"{p}transformer_decoder.layers.{i}.", x, memory, self_bias, mem_bias, cfg.nhead, drop, cfg.dropout)
     w = sd[p + "out_layer.weight"][:, :, 0]  # Conv1d k=1 head, decoder.py:98-102,145-146
     return (F.linear(x, w, sd[p + "out_layer.bias"])).permute(0, 2, 1).contiguous()
 
@@ -249,11 +315,12 @@ def ce_loss(logits_bvt: Tensor, target: Tensor, pad_idx: int = 0) -> Tensor:
 # --------------------------------------------------------------------------------------
 
 
-def transformer_forward(sd: SD, x: Tensor, xl, y_in: Tensor, cfg: OracleCfg, max_h: int, max_w: int) -> Tensor:
+def transformer_forward(sd: SD, x: Tensor, xl, y_in: Tensor, cfg: OracleCfg, max_h: int, max_w: int,
+                        drop: Optional[DropPlan] = None) -> Tensor:
     """Transformer.forward, model.py:141-150."""
     pe = pe2d_table(cfg.d_model, math.ceil(max_h / HEIGHT_REDUCTION), math.ceil(max_w / WIDTH_REDUCTION))
-    mem = encode_to_memory(sd, "encoder.", pe, x)
-    return decoder(sd, "decoder.", y_in, mem, xl, cfg)
+    mem = encode_to_memory(sd, "encoder.", pe, x, drop, cfg)
+    return decoder(sd, "decoder.", y_in, mem, xl, cfg, drop)
 
 
 def greedy_decode(sd: SD, dec_prefix: str, memory: Tensor, sos: int, eos: int, max_len: int, cfg: OracleCfg,
@@ -277,12 +344,31 @@ def greedy_decode(sd: SD, dec_prefix: str, memory: Tensor, sos: int, eos: int, m
     return (toks, tops) if return_logits else toks
 
 
+def weighted_decode(sd_img: SD, sd_aud: SD, mem_img: Tensor, mem_aud: Tensor, sos: int, eos: int, max_len: int, cfg: OracleCfg,
+                    alpha: float = 0.5) -> List[int]:
+    """weighted_prediction, src/multimodal/weighted_multimodal/test.py:21-70: two unimodal models decoded in lock-step from
+    the same prefix; per step softmax of each model's last-position logits, alpha * p_img + (1 - alpha) * p_audio, argmax;
+    stops after emitting eos.  mem_*: each model's encoder memory [1, S, d] (test.py:28-44)."""
+    y_in = torch.tensor([[sos]], dtype=torch.long)
+    toks: List[int] = []
+    for _ in range(max_len):
+        pi = decoder(sd_img, "decoder.", y_in, mem_img, None, cfg)[0, :, -1].softmax(dim=-1)
+        pa = decoder(sd_aud, "decoder.", y_in, mem_aud, None, cfg)[0, :, -1].softmax(dim=-1)
+        tok = int((alpha * pi + (1 - alpha) * pa).argmax(dim=-1))
+        toks.append(tok)
+        if tok == eos:
+            break
+        y_in = torch.cat([y_in, torch.tensor([[tok]])], dim=1)
+    return toks
+
+
 # --------------------------------------------------------------------------------------
 # Multimodal  (src/transformer/model.py:268-726)
 # --------------------------------------------------------------------------------------
 
 
-def cross_attention(sd: SD, p: str, query: Tensor, len_query, key_value: Tensor, len_kv, nhead: int = 4) -> Tensor:
+def cross_attention(sd: SD, p: str, query: Tensor, len_query, key_value: Tensor, len_kv, nhead: int = 4,
+                    drop: Optional[DropPlan] = None, dp: float = 0.0) -> Tensor:
     """CrossAttention.forward, model.py:299-355.  The bool mask [B,La,Lb] with block
     [lq:, lkv:] = True is tiled with .repeat(nhead,1,1) (model.py:354), so batched head index
     b*nhead+h receives the mask of sample (b*nhead+h) % B  (reference quirk 2)."""
@@ -297,7 +383,7 @@ def cross_attention(sd: SD, p: str, query: Tensor, len_query, key_value: Tensor,
         bias = m[idx].view(b, nhead, la, lb)
     a = p + "attention."
     return mha(query, key_value, sd[a + "in_proj_weight"], sd[a + "in_proj_bias"],
-               sd[a + "out_proj.weight"], sd[a + "out_proj.bias"], nhead, bias)
+               sd[a + "out_proj.weight"], sd[a + "out_proj.bias"], nhead, bias, drop, dp)
 
 
 def _len_mask(n: int, lens) -> Tensor:
@@ -307,7 +393,7 @@ def _len_mask(n: int, lens) -> Tensor:
     return m
 
 
-def mixer(sd: SD, kind: str, xi: Tensor, xa: Tensor, xli, xla):
+def mixer(sd: SD, kind: str, xi: Tensor, xa: Tensor, xli, xla, drop: Optional[DropPlan] = None, dp: float = 0.0):
     """mixer_concat / mixer_attn_img / mixer_attn_audio / mixer_attn_both, model.py:644-726."""
     have = xli is not None and xla is not None
     if kind == "concat":
@@ -315,33 +401,34 @@ def mixer(sd: SD, kind: str, xi: Tensor, xa: Tensor, xli, xla):
         xl = torch.cat([_len_mask(xi.shape[1], xli), _len_mask(xa.shape[1], xla)], dim=1) if have else None
         return x, xl  # bool mask -> true -inf masking (model.py:663-672)
     if kind == "attn_img":  # q = audio, kv = image
-        return cross_attention(sd, "cross_attn.", xa, xla, xi, xli), (xla if have else None)
+        return cross_attention(sd, "cross_attn.", xa, xla, xi, xli, drop=drop, dp=dp), (xla if have else None)
     if kind == "attn_audio":  # q = image, kv = audio
-        return cross_attention(sd, "cross_attn.", xi, xli, xa, xla), (xli if have else None)
+        return cross_attention(sd, "cross_attn.", xi, xli, xa, xla, drop=drop, dp=dp), (xli if have else None)
     if kind == "attn_both":
         # model.py:723-725: variable shadowing -- the second attention uses the ALREADY
         # ATTENDED audio as key/value (quirk 3); one shared cross_attn module.
-        xa2, xla2 = mixer(sd, "attn_img", xi, xa, xli, xla)
-        xi2, xli2 = mixer(sd, "attn_audio", xi, xa2, xli, xla2)
+        xa2, xla2 = mixer(sd, "attn_img", xi, xa, xli, xla, drop, dp)
+        xi2, xli2 = mixer(sd, "attn_audio", xi, xa2, xli, xla2, drop, dp)
         return mixer(sd, "concat", xi2, xa2, xli2, xla2)
     raise ValueError(f"Invalid mixer type: {kind}")
 
 
 def multimodal_forward(sd: SD, xi: Tensor, xli, xa: Tensor, xla, y_in: Tensor, cfg: OracleCfg, mixer_type: str,
-                       max_img_hw: Tuple[int, int], max_audio_hw: Tuple[int, int], modality: str = "both") -> Tensor:
+                       max_img_hw: Tuple[int, int], max_audio_hw: Tuple[int, int], modality: str = "both",
+                       drop: Optional[DropPlan] = None) -> Tensor:
     """MultimodalTransformer.forward / encoder_forward, model.py:485-543 with the modality
     choice of apply_teacher_forcing_modality (model.py:561-575) passed in explicitly."""
     pe_i = pe2d_table(cfg.d_model, math.ceil(max_img_hw[0] / 16), math.ceil(max_img_hw[1] / 8))
     pe_a = pe2d_table(cfg.d_model, math.ceil(max_audio_hw[0] / 16), math.ceil(max_audio_hw[1] / 8))
-    mi = encode_to_memory(sd, "image_encoder.", pe_i, xi)
-    ma = encode_to_memory(sd, "audio_encoder.", pe_a, xa)
+    mi = encode_to_memory(sd, "image_encoder.", pe_i, xi, drop, cfg)
+    ma = encode_to_memory(sd, "audio_encoder.", pe_a, xa, drop, cfg)
     if modality == "image":
         mem, ml = mi, xli
     elif modality == "audio":
         mem, ml = ma, xla
     else:
-        mem, ml = mixer(sd, mixer_type, mi, ma, xli, xla)
-    return decoder(sd, "decoder.", y_in, mem, ml, cfg)
+        mem, ml = mixer(sd, mixer_type, mi, ma, xli, xla, drop, cfg.dropout)
+    return decoder(sd, "decoder.", y_in, mem, ml, cfg, drop)
 
 
 # --------------------------------------------------------------------------------------
@@ -350,12 +437,19 @@ def multimodal_forward(sd: SD, xi: Tensor, xli, xa: Tensor, xla, y_in: Tensor, c
 
 
 def adam_step(params: Sequence[Tensor], grads: Sequence[Tensor], exp_avg: Sequence[Tensor], exp_avg_sq: Sequence[Tensor],
-              step: int, lr: float = 1e-4, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
+              step, lr: float = 1e-4, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
     """torch.optim.Adam single-tensor math (torch optim/adam.py:347), as configured at
-    model.py:134-139 (no weight decay, no amsgrad).  ``step`` is 1-based.  In place."""
-    bc1 = 1.0 - b1**step
-    bc2 = 1.0 - b2**step
-    for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+    model.py:134-139 (no weight decay, no amsgrad).  ``step`` is 1-based.  In place.
+    A parameter whose gradient is None is SKIPPED -- no moment decay, no update, no step count (torch optim/adam.py
+    _init_group collects only p.grad is not None; Lightning zeroes with set_to_none): the modality-drop steps of
+    MultimodalTransformer leave one encoder and cross_attn without gradients (model.py:510-519).  ``step`` may therefore be a
+    list with one 1-based count per parameter (the caller increments the counts of the parameters that had a gradient)."""
+    steps = step if isinstance(step, (list, tuple)) else [step] * len(params)
+    for p, g, m, v, st in zip(params, grads, exp_avg, exp_avg_sq, steps):
+        if g is None:
+            continue
+        bc1 = 1.0 - b1**st
+        bc2 = 1.0 - b2**st
         m.mul_(b1).add_(g, alpha=1 - b1)
         v.mul_(b2).addcmul_(g, g, value=1 - b2)
         denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)

@@ -92,3 +92,120 @@ def test_shard_indices_matches_distributed_sampler():
                 s.set_epoch(epoch)
                 assert list(s) == got[r]
             assert sorted(set(sum(got, []))) == data
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The drop-in Trainer under world_size 2 (gloo): rank-0 parameter broadcast, sample sharding (DistributedSampler
+# semantics), MEAN gradient in the optimizer step, sharded evaluation with all-reduced metric counts.  The HIP kernels have
+# no CPU path, so the toy module below does its arithmetic with torch CPU ops and a plain-SGD optimizer that honours the
+# step(grad_scale=...) contract; everything else (FlatParams, GradReducer, GradBoundary, ShardedLoader, Trainer,
+# compute_metrics_sharded) is the product's own host code.
+
+N_TRAIN, N_VAL, BS, EPOCHS, LR = 13, 7, 2, 2, 0.1
+
+
+def _toy_classes():
+    from omr_a2s_multimodal_transformer_amd.lightning_shim import LightningModule
+    from omr_a2s_multimodal_transformer_amd.metrics import compute_metrics, compute_metrics_sharded
+    from omr_a2s_multimodal_transformer_amd.model import _Base
+    from omr_a2s_multimodal_transformer_amd.runtime import FlatModuleMixin
+
+    class FlatSGD:
+        def __init__(self, flat):
+            self.flat = flat
+
+        def zero_grad(self, set_to_none=False):
+            self.flat.grad.zero_()
+
+        def step(self, grad_scale=1.0):
+            self.flat.master.sub_(LR * grad_scale * self.flat.grad)
+
+    class Toy(FlatModuleMixin, LightningModule):
+        attach_reducer = _Base.attach_reducer
+        _boundary = _Base._boundary
+        _reducer = None
+
+        def __init__(self, seed):
+            super().__init__()
+            torch.manual_seed(seed)
+            self.encoder = nn.Linear(5, 7)
+            self.decoder = nn.Linear(7, 3)
+            self.Y, self.YHat = [], []
+
+        def configure_optimizers(self):
+            return FlatSGD(self.ensure_flat())
+
+        def training_step(self, batch, i):
+            x, y = batch
+            return ((self.decoder(self._boundary(torch.tanh(self.encoder(x)))) - y) ** 2).mean()
+
+        def validation_step(self, batch, i):
+            x, y = batch
+            self.Y.append([str(int(v)) for v in y])
+            self.YHat.append([str(int(v)) for v in x])
+
+        def on_validation_epoch_end(self, name="val"):
+            m = compute_metrics_sharded(self.Y, self.YHat) if self._reducer is not None else compute_metrics(self.Y, self.YHat)
+            self.Y.clear(); self.YHat.clear()
+            return m
+
+    return Toy
+
+
+def _toy_data():
+    g = torch.Generator().manual_seed(5)
+    train = [(torch.randn(5, generator=g), torch.randn(3, generator=g)) for _ in range(N_TRAIN)]
+    val = [(torch.randint(0, 4, (6,), generator=g), torch.randint(0, 4, (5,), generator=g)) for _ in range(N_VAL)]
+    return train, val
+
+
+def _collate(items):
+    return torch.stack([a for a, _ in items]), torch.stack([b for _, b in items])
+
+
+def _trainer_worker(rank, world, port, q):
+    from omr_a2s_multimodal_transformer_amd.ddp import ShardedLoader
+    from omr_a2s_multimodal_transformer_amd.lightning_shim import Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    Toy = _toy_classes()
+    m = Toy(seed=100 + rank)                   # ranks start from DIFFERENT parameters: the reducer must broadcast rank 0's
+    m.flatten_parameters(device="cpu")
+    train, val = _toy_data()
+    tr = Trainer(max_epochs=EPOCHS, check_val_every_n_epoch=1)
+    tr.fit(m, ShardedLoader(train, BS, _collate, shuffle=True, seed=3), val)
+    assert m._reducer is not None and tr.reducer is m._reducer
+    q.put((rank, m._flat.master.clone().numpy(), dict(tr.callback_metrics)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_world2_gloo_equals_single_process_mean_gradient_training():
+    from omr_a2s_multimodal_transformer_amd.metrics import compute_metrics
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    # single-process emulation: same shards, gradient = mean over ranks of the per-rank mean-loss gradients
+    Toy = _toy_classes()
+    ref = Toy(seed=100)
+    ref.flatten_parameters(device="cpu")
+    train, val = _toy_data()
+    for epoch in range(EPOCHS):
+        shards = [shard_indices(len(train), r, world, epoch=epoch, shuffle=True, seed=3) for r in range(world)]
+        for s in range(0, len(shards[0]), BS):
+            ref._flat.grad.zero_()
+            for r in range(world):
+                ref.training_step(_collate([train[j] for j in shards[r][s:s + BS]]), 0).backward()
+            ref._flat.master.sub_(LR * (1.0 / world) * ref._flat.grad)
+    for rank, master, metrics in got:
+        assert torch.allclose(torch.from_numpy(master), ref._flat.master, rtol=1e-5, atol=1e-6), rank
+        want = compute_metrics([[str(int(v)) for v in y] for _, y in val], [[str(int(v)) for v in x] for x, _ in val])
+        assert metrics == {f"val_{k}": v for k, v in want.items()}, (rank, metrics, want)
+    assert (got[0][1] == got[1][1]).all()

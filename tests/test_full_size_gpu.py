@@ -1,13 +1,19 @@
-"""Parity at BASELINE.json's full sizes (C2: 256x2048 image, T=512, 6 layers, d_model=256, V=6997), where the CPU oracle
-is too slow to be the checker: size-independent properties of the reference's math instead.
+"""Parity at BASELINE.json's full sizes, where the CPU oracle is too slow to be the checker: size-independent properties of
+the reference's math instead.  What is run (stated per test):
 
-  * batch-permutation equivariance: every op on the path is per-sample (InstanceNorm, attention, row-wise linears), so
-    permuting the batch permutes the logits.  Not to the bit: the InstanceNorm statistics are reduced with (fp64) atomics
-    whose order varies from launch to launch, so the check is 1e-5 absolute on O(1) logits, two orders below the
-    north-star tolerance;
-  * gradient linearity: d(2L)/dw = 2 dL/dw (one backward pass with a scaled loss against two accumulated passes);
-  * the bf16 throughput mode tracks the fp32 parity mode at full size;
-  * KV-cached greedy decode is covered at S=4096 by tests/test_model_gpu.py::test_kv_cached_decode_matches_full_rerun_bf16_long.
+  C2  image model: 256x2048 image (S = 4096 memory tokens), T = 512, **6 layers**, d_model 256, V = 6997 -- the benchmark's
+      model exactly; batch 2-3 instead of 32 (every op on the path is per-sample, so the batch size only repeats the work).
+  C3  audio model: the reference's 195-bin log-STFT input 195x512 (S = 13*64 = 832) and BASELINE's 80-mel variant 80x1024
+      (S = 5*128 = 640), same 6-layer decoder.
+
+Properties:
+  * batch-permutation equivariance, TO THE BIT: every op is per-sample and every reduction (InstanceNorm statistics included,
+    now a fixed-order slot reduction) has an order that does not depend on the sample's position in the batch;
+  * run-to-run determinism of the forward pass and of the data-gradient chain: two identical training passes give gradients
+    that differ only by the fp32 atomics of the weight-gradient reductions (<= 1e-5 relative L2 per tensor);
+  * gradient linearity: d(2L)/dw = 2 dL/dw;
+  * the bf16 throughput mode tracks the fp32 parity mode;
+  * KV-cached greedy decode == the reference-style full re-run (C3 here; S = 4096 in tests/test_model_gpu.py).
 """
 import random
 
@@ -20,43 +26,72 @@ from omr_a2s_multimodal_transformer_amd import synthetic as syn  # noqa: E402
 from omr_a2s_multimodal_transformer_amd.config import ModelConfig  # noqa: E402
 
 DEV = "cuda:0"
-H, W, T, V = 256, 2048, 512, syn.GRANDSTAFF_VOCAB
+T, V, L = 512, syn.GRANDSTAFF_VOCAB, 6
+C2 = (256, 2048)
+C3_STFT, C3_MEL = (195, 512), (80, 1024)
 NO_DROP = dict(dropout=0.0, encoder_dropout=0.0)
 
 
-def make(cfg, seed=3):
+def make(hw, cfg, seed=3, max_seq=T):
     from omr_a2s_multimodal_transformer_amd.model import Transformer
     w2i, i2w = syn.make_vocab(V)
-    m = Transformer(H, W, T, w2i, i2w, attn_window=-1, config=cfg)
+    m = Transformer(hw[0], hw[1], max_seq, w2i, i2w, attn_window=-1, config=cfg)
     sd = syn.seeded_state_dict(syn.transformer_shapes(V, cfg.d_model, cfg.ff_dim, cfg.num_layers), seed, mode="torch_default")
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected
     m.flatten_parameters()
+    assert len(m.decoder.transformer_decoder.layers) == cfg.num_layers
     return m, w2i
 
 
-def batch(w2i, B, seed):
-    return tuple(t.to(DEV) for t in syn.synthetic_unimodal_batch(B, H, W, T, V, w2i["<sos>"], w2i["<eos>"], seed=seed))
+def batch(w2i, hw, B, seed, pad_value=1.0):
+    return tuple(t.to(DEV) for t in syn.synthetic_unimodal_batch(B, hw[0], hw[1], T, V, w2i["<sos>"], w2i["<eos>"], seed=seed, pad_value=pad_value))
 
 
-def test_c2_batch_permutation_equivariance_fp32():
-    m, w2i = make(ModelConfig(**NO_DROP))
+@pytest.mark.parametrize("hw,pad", [(C2, 1.0), (C3_STFT, 0.0), (C3_MEL, 0.0)])
+def test_batch_permutation_equivariance_fp32_bit_exact(hw, pad):
+    m, w2i = make(hw, ModelConfig(num_layers=L, **NO_DROP))
     m.eval()
-    x, xl, y_in, _ = batch(w2i, 3, seed=11)
+    x, xl, y_in, _ = batch(w2i, hw, 3, seed=11, pad_value=pad)
     perm = torch.tensor([2, 0, 1], device=DEV)
     with torch.no_grad():
         a = m(x, xl, y_in)
         b = m(x[perm].contiguous(), xl[perm].contiguous(), y_in[perm].contiguous())
+        a2 = m(x, xl, y_in)
     assert tuple(a.shape) == (3, V, T) and torch.isfinite(a).all()
-    assert (a[perm] - b).abs().max().item() <= 1e-5, f"max |diff| = {(a[perm] - b).abs().max().item():.3e}"
+    assert torch.equal(a, a2), "the forward pass is not deterministic from run to run"
+    assert torch.equal(a[perm], b), f"max |diff| = {(a[perm] - b).abs().max().item():.3e}"
+
+
+def test_c2_two_identical_training_passes_agree_to_atomics_noise_fp32():
+    m, w2i = make(C2, ModelConfig(num_layers=L, **NO_DROP))
+    m.train()
+    m.teacher_forcing_prob = 0.0
+    x, xl, y_in, y_out = batch(w2i, C2, 2, seed=12)
+    grads, losses = [], []
+    for _ in range(2):
+        random.seed(0)
+        m.zero_grad()
+        loss = m.compute_loss(m(x, xl, y_in), y_out)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append(m._flat.grad.clone())
+        losses.append(loss.detach().clone())
+    assert torch.equal(losses[0], losses[1])
+    for n, (o, c) in m._flat.offsets.items():
+        r = grads[0][o:o + c]
+        if r.abs().max() == 0:
+            continue
+        rel = ((grads[1][o:o + c] - r).norm() / r.norm()).item()
+        assert rel < 1e-5, (n, rel)         # weight-gradient reductions use fp32 atomics (order varies); nothing upstream of them may move
 
 
 def test_c2_gradient_linearity_fp32():
-    m, w2i = make(ModelConfig(**NO_DROP))
+    m, w2i = make(C2, ModelConfig(num_layers=L, **NO_DROP))
     m.train()
     m.teacher_forcing_prob = 0.0
     random.seed(0)
-    x, xl, y_in, y_out = batch(w2i, 2, seed=12)
+    x, xl, y_in, y_out = batch(w2i, C2, 2, seed=12)
     m.zero_grad()
     (2.0 * m.compute_loss(m(x, xl, y_in), y_out)).backward()
     g2 = m._flat.grad.clone()
@@ -65,20 +100,44 @@ def test_c2_gradient_linearity_fp32():
         m.compute_loss(m(x, xl, y_in), y_out).backward()
     g11 = m._flat.grad
     assert torch.isfinite(g2).all() and g2.abs().max() > 0
-    # fp32 atomics reorder sums between passes (and flip a ReLU here and there through the InstanceNorm statistics):
-    # compare in relative L2 at the north-star tolerance, and bound the worst element at 1 % of the gradient scale
     rel = ((g2 - g11).norm() / g2.norm()).item()
     worst = ((g2 - g11).abs().max() / g2.abs().max()).item()
-    assert rel < 1e-3 and worst < 1e-2, (rel, worst)
+    assert rel < 1e-4 and worst < 1e-3, (rel, worst)
 
 
-def test_c2_bf16_mode_tracks_fp32_mode():
-    m32, w2i = make(ModelConfig(**NO_DROP))
-    m16, _ = make(ModelConfig(compute_dtype="bf16", **NO_DROP))
+@pytest.mark.parametrize("hw,pad", [(C2, 1.0), (C3_STFT, 0.0)])
+def test_bf16_mode_tracks_fp32_mode(hw, pad):
+    m32, w2i = make(hw, ModelConfig(num_layers=L, **NO_DROP))
+    m16, _ = make(hw, ModelConfig(num_layers=L, compute_dtype="bf16", **NO_DROP))
     m32.eval(); m16.eval()
-    x, xl, y_in, y_out = batch(w2i, 2, seed=13)
+    x, xl, y_in, y_out = batch(w2i, hw, 2, seed=13, pad_value=pad)
     with torch.no_grad():
         l32 = m32.compute_loss(m32(x, xl, y_in), y_out)
         l16 = m16.compute_loss(m16(x, xl, y_in), y_out)
     assert torch.isfinite(l32) and torch.isfinite(l16)
     assert abs(float(l16) - float(l32)) / abs(float(l32)) < 2e-2, (float(l16), float(l32))
+
+
+@pytest.mark.parametrize("hw", [C3_STFT, C3_MEL])
+def test_c3_audio_model_trains_and_decodes(hw):
+    """The audio-only configuration at its own shapes: one bf16 training step with dropout ON is finite and moves the
+    parameters; KV-cached greedy decode equals the reference-style full re-run (fp32)."""
+    m, w2i = make(hw, ModelConfig(num_layers=L, compute_dtype="bf16"))
+    m.train()
+    m.teacher_forcing_prob = 0.2
+    random.seed(1)
+    bt = batch(w2i, hw, 4, seed=14, pad_value=0.0)
+    opt = m.configure_optimizers()
+    opt.zero_grad()
+    before = m._flat.master.clone()
+    loss = m.training_step(bt, 0)
+    loss.backward()
+    opt.step()
+    assert torch.isfinite(loss) and torch.isfinite(m._flat.master).all() and not torch.equal(before, m._flat.master)
+    m32, _ = make(hw, ModelConfig(num_layers=L), max_seq=24)
+    m32.eval()
+    mem = m32.encode(bt[0][:1])
+    assert mem.shape[1] == ((hw[0] + 15) // 16) * ((hw[1] + 7) // 8)
+    a, _ = m32._greedy(mem, use_cache=True)
+    b, _ = m32._greedy(mem, use_cache=False)
+    assert a == b and len(a) >= 1

@@ -458,11 +458,11 @@ def test_conv3x3_fused_dropout_and_instnorm_reductions(dtype, channel_mode):
     w = q(rnd((C, 3, 3, C), 91) / 12, dtype).to(dev(), dtype)
     bias = rnd((C,), 92).to(dev())
     y_plain = k.conv3x3(x, w, bias, relu=True)
-    ws = torch.zeros((B, C, 2), dtype=torch.float64, device=dev())
-    y = k.conv3x3(x, w, bias, relu=True, drop=(0.5, 77, channel_mode), stat_mode=1, stat_ws=ws)
+    ws, slots = k.conv_stat_ws(B, H, W, C, dev())
+    y = k.conv3x3(x, w, bias, relu=True, drop=(0.5, 77, channel_mode), stat_mode=1, stat_ws=ws, stat_slots=slots)
     ref = k.dropout(y_plain, 0.5, 77, channel_mode)
     torch.testing.assert_close(y.float(), ref.float(), **tol(dtype))
-    mean, rstd = k.instnorm_finalize(ws, H * W)
+    mean, rstd = k.instnorm_finalize(ws, slots, B, C, H * W)
     mean_ref, rstd_ref = k.instnorm_stats(y)
     torch.testing.assert_close(mean, mean_ref, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(rstd, rstd_ref, rtol=1e-4, atol=1e-4)
@@ -471,11 +471,25 @@ def test_conv3x3_fused_dropout_and_instnorm_reductions(dtype, channel_mode):
     wd = k.conv3x3_weight_flip(w)
     dxh_ref = k.conv3x3(g, wd, None, out_hw=(H, W))
     dx_ref = k.instnorm_bwd(dxh_ref, y, mean, rstd, relu_mask=True, relu_scale=2.0)
-    ws2 = torch.zeros((B, C, 2), dtype=torch.float64, device=dev())
-    dxh = k.conv3x3(g, wd, None, out_hw=(H, W), stat_mode=2, stat_ws=ws2, stat_x=y, stat_stats=(mean, rstd))
+    ws2, slots2 = k.conv_stat_ws(B, H, W, C, dev())
+    dxh = k.conv3x3(g, wd, None, out_hw=(H, W), stat_mode=2, stat_ws=ws2, stat_slots=slots2, stat_x=y, stat_stats=(mean, rstd))
     assert torch.equal(dxh, dxh_ref)
-    dx = k.instnorm_bwd_apply(dxh, y, mean, rstd, ws2, relu_mask=True, relu_scale=2.0)
+    dx = k.instnorm_bwd_apply(dxh, y, mean, rstd, ws2, slots2, relu_mask=True, relu_scale=2.0)
     torch.testing.assert_close(dx.float(), dx_ref.float(), **tol(dtype, 2))
+    # the statistics are a fixed-order reduction (no atomics): repeated launches agree to the bit, also with fewer slots
+    # than the launch would like to use (the grid is clamped to the slot count)
+    for s_use in (slots, 2):
+        runs = []
+        for _ in range(3):
+            wsr = torch.zeros_like(ws)
+            k.conv3x3(x, w, bias, relu=True, drop=(0.5, 77, channel_mode), stat_mode=1, stat_ws=wsr, stat_slots=s_use)
+            runs.append(k.instnorm_finalize(wsr, s_use, B, C, H * W))
+        assert all(torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]) for r in runs[1:])
+        torch.testing.assert_close(runs[0][0], mean_ref, rtol=1e-4, atol=1e-5)
+    a1, a2 = k.instnorm_stats(y), k.instnorm_stats(y)
+    assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1])
+    d1 = k.instnorm_bwd(dxh_ref, y, mean, rstd, relu_mask=True, relu_scale=2.0)
+    assert torch.equal(d1, dx_ref)
 
 
 # ------------------------------------------------------------------------------------------------ audio front end

@@ -185,9 +185,13 @@ def test_multimodal_matches_reference_golden(golden, mt, modality):
     ref = g[f"{mt}_{modality}_grad_norms"]
     got = grad_norms(m, names)
     ref = np.where(ref < 0, 0.0, ref)  # reference: unused parameters have grad None; here their flat slice stays zero
-    # gradient NORMS of the earliest layers move by a few 1e-3 when a near-zero ReLU pre-activation flips sign under a
-    # different fp32 summation order (tiny 2x6 feature maps here); logits and loss above stay within 1e-3.
+    # Hard bound 1e-2 on every tensor, 1e-3 on the typical one.  A near-zero ReLU pre-activation that flips its mask between
+    # two fp32 implementations moves a layer's gradient (and everything upstream) by ~1/sqrt(N) of its norm -- measured between
+    # the reference and the oracle themselves, both torch CPU (tools/relu_flip_probe.py; tests/test_dropout_parity_gpu.py uses
+    # an fp64 run as the arbiter).  The non-degenerate shapes are in tests/test_round2_gpu.py.
     np.testing.assert_allclose(got, ref, rtol=1e-2, atol=1e-6)
+    live = ref > 0
+    assert np.median(np.abs(got[live] - ref[live]) / ref[live]) < 1e-3
 
 
 @pytest.mark.parametrize("win", [-1, 4])
@@ -392,11 +396,9 @@ def test_side_stream_weight_gradients_are_complete_and_equal_to_in_order_ones():
         WgradStream.enabled = True
     ref = grads[False][0]
     assert ref.abs().max() > 0
-    # Decoder-side gradients (every side-stream GEMM of the decoder) must agree to fp32-atomics noise.  Encoder gradients are
-    # compared at 5 %: independent of the stream layout, two runs of the SAME configuration differ there by up to ~1 % in a
-    # few discrete patterns, because the constant padding of the synthetic images normalises to +-1e-8 under InstanceNorm
-    # (fp64 atomics, order varies) and the ReLU mask of such an element flips -- the loss does not move.  A lost or torn
-    # weight gradient would be an O(1) error in its own slice, which both bounds catch.
+    # Every gradient must agree to fp32-atomics noise, encoder included: the InstanceNorm statistics are a fixed-order slot
+    # reduction (no atomics), so the forward pass and the data-gradient chain are bit-identical from run to run and only the
+    # weight-gradient sums (fp32 atomics, order varies) differ in their last bits.
     for g in grads[True] + grads[False][1:]:
         for n, (o, c) in m._flat.offsets.items():
             r = ref[o:o + c]
@@ -404,7 +406,7 @@ def test_side_stream_weight_gradients_are_complete_and_equal_to_in_order_ones():
                 continue
             assert g[o:o + c].abs().max() > 0, f"{n}: gradient missing"
             rel = ((g[o:o + c] - r).norm() / r.norm()).item()
-            assert rel < (1e-5 if n.startswith("decoder.") else 5e-2), (n, rel)
+            assert rel < 1e-5, (n, rel)
 
 
 @pytest.mark.parametrize("dtype,win", [("fp32", -1), ("fp32", 4), ("bf16", -1)])

@@ -57,11 +57,11 @@ def test_overlapped_bucket_all_reduce_equals_the_plain_step(one_rank_group):
         results.append((m._flat.master.clone(), m._flat.grad.clone()))
     (p0, g0), (p1, g1) = results
     assert torch.isfinite(p1).all() and g1.abs().max() > 0
-    # same tolerance logic as test_side_stream_weight_gradients...: decoder slices to atomics noise, encoder slices loosely
+    # every slice to fp32-atomics noise (the InstanceNorm statistics are a deterministic reduction: no run-to-run ReLU flips)
     for n, (o, c) in m._flat.offsets.items():
         r = g0[o:o + c]
         if r.abs().max() == 0:
             continue
         rel = ((g1[o:o + c] - r).norm() / r.norm()).item()
-        assert rel < (1e-5 if n.startswith("decoder.") else 5e-2), (n, rel)
+        assert rel < 1e-5, (n, rel)
     assert ((p1 - p0).abs().max()).item() < 5e-4      # two Adam steps of lr 1e-4: parameters can differ by at most ~2 lr

@@ -1,0 +1,159 @@
+"""Round-2 GPU parity: the HIP modules against the reference's round-2 golden vectors (tests/golden/gen_golden_r2.py):
+non-degenerate shapes (deepest feature maps 4x20 / 13x12), weighted late-fusion decode, Adam with skipped sub-modules."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from omr_a2s_multimodal_transformer_amd import synthetic as syn  # noqa: E402
+from omr_a2s_multimodal_transformer_amd.config import ModelConfig  # noqa: E402
+
+DEV = "cuda:0"
+NO_DROP = dict(dropout=0.0, encoder_dropout=0.0)
+IMG_HW, AUD_HW = (64, 160), (195, 96)
+
+
+def rnd(shape, seed):
+    return torch.rand(shape, generator=torch.Generator().manual_seed(seed))
+
+
+def load(module, shapes, seed):
+    sd = syn.seeded_state_dict(shapes, seed)
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    assert not unexpected and all(m.endswith("pe") or m.endswith("pe_hwc") for m in missing)
+    return sd
+
+
+def check_grad_norms(model, names, ref):
+    """Norms against the reference's: hard 1e-2 on every tensor, 1e-3 on the typical one (single ReLU-mask flips between two
+    fp32 implementations move whole tensors by ~1/sqrt(N): tests/test_dropout_parity_gpu.py has the measurement)."""
+    ps = dict(model.named_parameters())
+    assert names == [n for n, _ in model.named_parameters()]
+    got = np.array([float(ps[n].grad.detach().double().norm()) for n in names])
+    ref = np.where(ref < 0, 0.0, ref)         # reference: unused parameters have grad None; here their slice stays zero
+    assert np.array_equal(got == 0, ref == 0)
+    live = ref > 0
+    rel = np.abs(got[live] - ref[live]) / ref[live]
+    assert rel.max() < 1e-2 and np.median(rel) < 1e-3, (rel.max(), np.median(rel), names[int(np.argmax(np.where(live, np.abs(got - ref) / np.maximum(ref, 1e-30), 0)))])
+
+
+def test_unimodal_forward_backward_matches_reference_golden_nondegenerate(golden):
+    from omr_a2s_multimodal_transformer_amd.model import Transformer
+    g = golden("f13_nondegenerate")
+    V = 50
+    w2i, i2w = syn.make_vocab(V)
+    m = Transformer(IMG_HW[0], IMG_HW[1], 16, w2i, i2w, config=ModelConfig(**NO_DROP))
+    load(m, syn.transformer_shapes(V), 41)
+    m.flatten_parameters()
+    m.train()
+    random.seed(0)
+    x, xl, y_in, y_out = syn.synthetic_unimodal_batch(2, IMG_HW[0], IMG_HW[1], 12, V, w2i["<sos>"], w2i["<eos>"], seed=9)
+    m.zero_grad()
+    logits = m(x.to(DEV), xl, y_in)
+    np.testing.assert_allclose(logits.detach().float().cpu().numpy(), g["uni_logits"], rtol=1e-3, atol=2e-4)
+    loss = m.compute_loss(logits, y_out.to(DEV))
+    np.testing.assert_allclose(float(loss), float(g["uni_loss"]), rtol=1e-4)
+    loss.backward()
+    check_grad_norms(m, [str(n) for n in g["uni_grad_names"]], g["uni_grad_norms"])
+
+
+@pytest.mark.parametrize("mt,modality", [("concat", "both"), ("attn_img", "both"), ("attn_audio", "both"), ("attn_both", "both"),
+                                         ("attn_both", "image"), ("attn_both", "audio")])
+def test_multimodal_matches_reference_golden_nondegenerate(golden, mt, modality):
+    from omr_a2s_multimodal_transformer_amd.model import MultimodalTransformer
+    g = golden("f13_nondegenerate")
+    V = 40
+    w2i, i2w = syn.make_vocab(V)
+    m = MultimodalTransformer(IMG_HW[0], IMG_HW[1], AUD_HW[0], AUD_HW[1], 12, w2i, i2w, mixer_type=mt, config=ModelConfig(**NO_DROP))
+    load(m, syn.multimodal_shapes(V, mt), 51)
+    m.flatten_parameters()
+    m.train()
+    xi, xli, y_in, y_out = syn.synthetic_unimodal_batch(3, IMG_HW[0], IMG_HW[1], 11, V, w2i["<sos>"], w2i["<eos>"], seed=16)
+    xa, xla, _, _ = syn.synthetic_unimodal_batch(3, AUD_HW[0], AUD_HW[1], 11, V, w2i["<sos>"], w2i["<eos>"], seed=17, pad_value=0.0)
+    m.apply_teacher_forcing_modality = lambda: modality
+    m.zero_grad()
+    logits = m(xi.to(DEV), xli, xa.to(DEV), xla, y_in, apply_teacher_forcing_modality=True)
+    np.testing.assert_allclose(logits.detach().float().cpu().numpy(), g[f"{mt}_{modality}_logits"], rtol=1e-3, atol=2e-4)
+    loss = m.compute_loss(logits, y_out.to(DEV))
+    np.testing.assert_allclose(float(loss), float(g[f"{mt}_{modality}_loss"]), rtol=1e-4)
+    loss.backward()
+    check_grad_norms(m, [str(n) for n in g[f"{mt}_{modality}_grad_names"]], g[f"{mt}_{modality}_grad_norms"])
+    assert m._touched == {"both": None, "image": ("image_encoder", "decoder"), "audio": ("audio_encoder", "decoder")}[modality]
+
+
+@pytest.mark.parametrize("alpha", [0.0, 0.3, 0.5, 1.0])
+def test_weighted_late_fusion_decode_matches_reference_tokens(golden, alpha):
+    """weighted_prediction (src/multimodal/weighted_multimodal/test.py:21-70): bit-exact token ids for every alpha."""
+    from omr_a2s_multimodal_transformer_amd.model import Transformer
+    from omr_a2s_multimodal_transformer_amd.weighted_fusion import weighted_prediction
+    g = golden("f15_weighted")
+    V = 30
+    w2i, i2w = syn.make_vocab(V)
+    img = Transformer(64, 128, 14, w2i, i2w).eval()
+    load(img, syn.transformer_shapes(V), 81)
+    img.flatten_parameters()
+    aud = Transformer(195, 64, 14, w2i, i2w).eval()
+    load(aud, syn.transformer_shapes(V), 82)
+    aud.flatten_parameters()
+    xi, xa = rnd((1, 1, 64, 128), 801).to(DEV), rnd((1, 1, 195, 64), 802).to(DEV)
+    words = weighted_prediction(xi, xa, img, aud, alpha=alpha)
+    np.testing.assert_array_equal(np.array([w2i[w] for w in words]), g[f"a{alpha}_tokens"])
+    assert float(np.min(g[f"a{alpha}_margin"])) > 1e-6
+    if alpha == 1.0:                        # alpha = 1: the image model's own greedy decode
+        assert words == img._greedy(img.encode(xi))[0]
+    if alpha == 0.0:
+        assert words == aud._greedy(aud.encode(xa))[0]
+
+
+def test_weighted_argmax_kernel_matches_torch():
+    from omr_a2s_multimodal_transformer_amd import kernels as K
+    for n, alpha in ((6997, 0.3), (30, 0.5), (257, 1.0), (1000, 0.0)):
+        la, lb = (rnd((n,), 5) * 8 - 4).to(DEV), (rnd((n,), 6) * 8 - 4).to(DEV)
+        idx, prob = K.weighted_argmax(la, lb, alpha)
+        mix = alpha * la.cpu().softmax(-1) + (1 - alpha) * lb.cpu().softmax(-1)
+        assert int(idx) == int(mix.argmax()), (n, alpha)
+        torch.testing.assert_close(prob.cpu()[0], mix.max(), rtol=1e-5, atol=1e-8)
+    la = torch.zeros(64, device=DEV)
+    assert int(K.weighted_argmax(la, la.clone(), 0.5)[0]) == 0          # ties: first index
+
+
+def test_adam_skips_submodules_without_gradient_like_the_reference(golden):
+    """Five Adam steps of the multimodal model with modality drops (both, image, image, audio, both): parameters of the
+    sub-modules that took no part in a step keep their values, moments and step counts (torch.optim.Adam with grad None)."""
+    from omr_a2s_multimodal_transformer_amd.model import MultimodalTransformer
+    g = golden("f17_adam_multimodal")
+    V = 40
+    w2i, i2w = syn.make_vocab(V)
+    m = MultimodalTransformer(32, 48, 35, 40, 12, w2i, i2w, mixer_type="attn_both", config=ModelConfig(**NO_DROP))
+    sd0 = load(m, syn.multimodal_shapes(V, "attn_both"), 51)
+    m.flatten_parameters()
+    m.train()
+    xi, xli, y_in, y_out = syn.synthetic_unimodal_batch(3, 32, 48, 9, V, w2i["<sos>"], w2i["<eos>"], seed=6)
+    xa, xla, _, _ = syn.synthetic_unimodal_batch(3, 35, 40, 9, V, w2i["<sos>"], w2i["<eos>"], seed=7, pad_value=0.0)
+    xi, xa, y_out = xi.to(DEV), xa.to(DEV), y_out.to(DEV)
+    opt = m.configure_optimizers()
+    losses = []
+    frozen = None
+    for modality in [str(s) for s in g["seq"]]:
+        m.apply_teacher_forcing_modality = lambda mod=modality: mod
+        opt.zero_grad()
+        before = m._flat.master.clone()
+        loss = m.compute_loss(m(xi, xli, xa, xla, y_in, apply_teacher_forcing_modality=True), y_out)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        rng = opt.ranges
+        if modality == "image":             # the audio encoder and the mixer did not move at all
+            for name in ("audio_encoder", "cross_attn"):
+                b, e = rng[name]
+                assert torch.equal(before[b:e], m._flat.master[b:e]), name
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-3)
+    assert opt.steps == {"image_encoder": 4, "audio_encoder": 3, "decoder": 5, "cross_attn": 2}
+    ps = dict(m.named_parameters())
+    for k, da, h in zip(g["sel"], g["delta_abs"], g["heads"]):
+        d = (ps[str(k)].detach().cpu() - sd0[str(k)]).double()
+        np.testing.assert_allclose(float(d.abs().sum()), da, rtol=2e-2, err_msg=str(k))       # Adam's sign-like update amplifies tiny gradient differences
+        np.testing.assert_allclose(d.flatten()[:8].numpy(), h, rtol=0.2, atol=2e-5, err_msg=str(k))
