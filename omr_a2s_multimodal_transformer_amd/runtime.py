@@ -56,12 +56,25 @@ class WgradStream:
     stream's position at every hand-off (its inputs were produced there); the main stream waits for the side stream once,
     when the backward pass ends (autograd engine callback), and before anything else that touches the flat gradient buffer
     (all-reduce buckets, zero_grad, Adam -- they call join()).  Tensors read on the side stream are recorded on it so the
-    caching allocator does not hand their memory out early."""
+    caching allocator does not hand their memory out early, AND a reference to each of them is held until the side-stream
+    kernel that reads it has finished: autograd accumulates a second incoming gradient IN PLACE into a buffer nobody else
+    references (a residual add hands the same gradient tensor to both of its inputs), and that in-place add on the main
+    stream would otherwise race with the weight-gradient GEMM still reading the tensor on the side stream (seen as 4-30 %
+    errors in the point_conv weight gradients in front of the encoder's residual adds when the side stream lags)."""
 
     enabled = True
     kinds = {"linear", "depthwise", "cross_kv"}     # which weight gradients take the side stream (tests narrow this)
     _side = {}
     _pending = {}          # device index -> the stream that has to wait
+    _hold = []             # (event recorded behind the side-stream kernel, the tensors it reads)
+
+    @classmethod
+    def _release_finished(cls, everything: bool = False) -> None:
+        if everything:
+            cls._hold.clear()
+        else:
+            while cls._hold and cls._hold[0][0].query():
+                cls._hold.pop(0)
 
     @classmethod
     def run(cls, kind, fn, *tensors) -> None:
@@ -77,8 +90,12 @@ class WgradStream:
         side.wait_stream(main)
         with torch.cuda.stream(side):
             fn()
+            ev = torch.cuda.Event()
+            ev.record(side)
         for t in tensors:
             t.record_stream(side)
+        cls._release_finished()
+        cls._hold.append((ev, tensors))
         first = not cls._pending
         cls._pending[dev] = main
         if first:
@@ -92,6 +109,7 @@ class WgradStream:
         for dev, main in list(cls._pending.items()):
             main.wait_stream(cls._side[dev])
         cls._pending.clear()
+        cls._release_finished(everything=True)      # the main stream is ordered behind every side-stream read now
 
 
 class FlatModuleMixin:

@@ -8,13 +8,16 @@ omr_attn_dropout_mask) and injected into oracle.ref_cpu.DropPlan, whose train-mo
 reference itself (tests/golden/f12_dropout.npz, tests/test_oracle_golden_r2.py).  Forward, loss and every parameter
 gradient are compared, fp32.
 
-Gradient criterion.  fp32 gradients of this network are only reproducible to ~1e-3 between ANY two correct fp32
+Gradient criterion.  fp32 gradients of this network are only reproducible to ~1e-3..1e-2 between ANY two correct fp32
 implementations: one ReLU pre-activation within rounding noise of zero flips its mask and moves that layer's gradient (and
-everything upstream) by 1/sqrt(N) of its norm (tools/relu_flip_probe.py: the reference and the oracle, both torch CPU,
-differ by 2.5e-3 on such tensors; each is ~1.2e-3 from the fp64 result).  So the arbiter is the oracle run in fp64 with the
-same masks: the HIP gradients must be as close to it as the CPU fp32 gradients are (RMS over tensors within 3x, floor 1e-3),
-with a hard 1e-2 bound per tensor -- a wrong mask, a missing 1/(1-p) or a mask/element misalignment in any backward kernel
-is an O(1) error in the tensors downstream of it.
+everything upstream) by ~1/sqrt(N) of its norm -- 6e-3 for one element of a 3x128x4x20 map (tools/relu_flip_probe.py: the
+reference and the oracle, both torch CPU, differ by 2.5e-3 on such tensors; each is ~1.2e-3 from the fp64 result).  So the
+arbiter is the oracle run in fp64 with the same masks, and the yardstick is the CPU fp32 arithmetic itself: the fp32 oracle
+is run on the exact input AND on inputs jittered by one part in 5e6 (a few ulp: other near-zero elements flip), and the
+distance of those runs from the fp64 gradient measures how reproducible this configuration is.  The HIP gradients must be
+as close to the fp64 gradient as that: RMS over tensors within 3x of the worst CPU run (floor 1e-3), worst tensor within
+3x of the worst CPU tensor (floor 1e-2).  A wrong mask, a missing 1/(1-p) or a mask/element misalignment in any backward
+kernel is an O(1) error in the tensors downstream of it.
 """
 import random
 
@@ -45,9 +48,9 @@ def plan_from_trace(trace, dtype=torch.float32):
                 m = K.attn_dropout_mask(B, H, T, S, p, seed, DEV).float() / (1.0 - p)
             elif kind == "nhwc":
                 B, C, Hh, W = shape
-                m = K.dropout(torch.ones((B, Hh, W, C), device=DEV), p, seed, channel).permute(0, 3, 1, 2)
+                m = K.dropout(torch.ones((B, Hh, W, C), device=DEV, dtype=torch.float32), p, seed, channel).permute(0, 3, 1, 2)
             else:
-                m = K.dropout(torch.ones(shape, device=DEV), p, seed, False)
+                m = K.dropout(torch.ones(shape, device=DEV, dtype=torch.float32), p, seed, False)
             cache[site] = m.cpu().contiguous()
         return cache[site].to(dtype)
 
@@ -72,6 +75,10 @@ def check_against_oracle(model, logits, loss, fwd, sd, trace, rseed):
     lo32, loss32, g32 = oracle_run(fwd, sd, torch.float32, trace)
     random.seed(rseed)
     _, _, g64 = oracle_run(fwd, sd, torch.float64, trace)
+    jittered = []
+    for k in range(2):                                 # the CPU fp32 arithmetic on inputs a few ulp away: its own flip statistics
+        random.seed(rseed)
+        jittered.append(oracle_run(lambda sdx, plan: fwd(sdx, plan, jitter=k + 1), sd, torch.float32, trace)[2])
     got = logits.detach().float().cpu()
     assert torch.isfinite(got).all()
     rel = ((got - lo32).norm() / lo32.norm()).item()
@@ -84,14 +91,22 @@ def check_against_oracle(model, logits, loss, fwd, sd, trace, rseed):
             assert float(p.grad.abs().max()) == 0.0, n
             continue
         e_hip.append(((p.grad.detach().double().cpu() - ref).norm() / ref.norm()).item())
-        e_cpu.append(((g32[n].double() - ref).norm() / ref.norm()).item())
+        e_cpu.append([((g[n].double() - ref).norm() / ref.norm()).item() for g in [g32] + jittered])
         names.append(n)
-    e_hip, e_cpu = np.array(e_hip), np.array(e_cpu)
+    e_hip, e_cpu = np.array(e_hip), np.array(e_cpu)          # [tensors], [tensors, 3 CPU runs]
     worst = int(np.argmax(e_hip))
-    assert e_hip.max() < 1e-2, (names[worst], e_hip[worst], e_cpu[worst])
-    rms_hip, rms_cpu = float(np.sqrt((e_hip ** 2).mean())), float(np.sqrt((e_cpu ** 2).mean()))
+    assert e_hip.max() <= max(1e-2, 3.0 * e_cpu.max()), (names[worst], e_hip[worst], e_cpu[worst], e_cpu.max())
+    rms_hip, rms_cpu = float(np.sqrt((e_hip ** 2).mean())), float(np.sqrt((e_cpu ** 2).mean(axis=0)).max())
     assert rms_hip <= max(1e-3, 3.0 * rms_cpu), (rms_hip, rms_cpu)
     return rms_hip, rms_cpu
+
+
+def jittered(x, k):
+    """x * (1 + 2e-7 * noise): a few ulp, seeded by k (k = 0: x itself)."""
+    if not k:
+        return x
+    g = torch.Generator().manual_seed(1000 + k)
+    return x * (1.0 + 2e-7 * torch.randn(x.shape, generator=g, dtype=torch.float32).to(x.dtype))
 
 
 def load(module, shapes, seed):
@@ -126,8 +141,8 @@ def test_unimodal_train_mode_matches_oracle_with_injected_masks(rseed, window):
     assert len(trace) == 9 + 1 + 1 + 6 * L and kinds.count("attn") == 2 * L and kinds.count("nhwc") == 10
     ocfg = R.OracleCfg(num_layers=L, attn_window=window)
 
-    def fwd(sdx, plan):
-        lo = R.transformer_forward(sdx, x.to(next(iter(sdx.values())).dtype), xl, y_in, ocfg, H, W, drop=plan)
+    def fwd(sdx, plan, jitter=0):
+        lo = R.transformer_forward(sdx, jittered(x, jitter).to(next(iter(sdx.values())).dtype), xl, y_in, ocfg, H, W, drop=plan)
         assert plan.sites == len(trace)
         return lo, R.ce_loss(lo, y_out)
 
@@ -168,9 +183,9 @@ def test_multimodal_train_mode_matches_oracle_with_injected_masks(mt, modality, 
     assert len(trace) == 2 * 10 + n_mixer + 1 + 6 * L
     ocfg = R.OracleCfg(num_layers=L)
 
-    def fwd(sdx, plan):
+    def fwd(sdx, plan, jitter=0):
         dt = next(iter(sdx.values())).dtype
-        lo = R.multimodal_forward(sdx, xi.to(dt), xli, xa.to(dt), xla, y_in, ocfg, mt, IMG, AUD, modality, drop=plan)
+        lo = R.multimodal_forward(sdx, jittered(xi, jitter).to(dt), xli, jittered(xa, 10 * jitter).to(dt), xla, y_in, ocfg, mt, IMG, AUD, modality, drop=plan)
         assert plan.sites == len(trace)
         return lo, R.ce_loss(lo, y_out)
 

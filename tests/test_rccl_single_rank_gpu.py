@@ -50,18 +50,26 @@ def test_overlapped_bucket_all_reduce_equals_the_plain_step(one_rank_group):
             if red is not None:
                 assert red.done[1] and not red.done[0]          # decoder bucket left during backward, encoder bucket not yet
                 red.finish()
+                if step == 0:
+                    first_grad = m._flat.grad.clone()
                 opt.step(grad_scale=red.grad_scale)
             else:
+                if step == 0:
+                    first_grad = m._flat.grad.clone()
                 opt.step(grad_scale=0.5)
         torch.cuda.synchronize()
-        results.append((m._flat.master.clone(), m._flat.grad.clone()))
-    (p0, g0), (p1, g1) = results
+        results.append((m._flat.master.clone(), first_grad, m._flat.grad.clone()))
+    (p0, f0, g0), (p1, f1, g1) = results
     assert torch.isfinite(p1).all() and g1.abs().max() > 0
-    # every slice to fp32-atomics noise (the InstanceNorm statistics are a deterministic reduction: no run-to-run ReLU flips)
+    # First step (identical parameters on both sides): every slice to fp32-atomics noise -- the forward pass and the
+    # data-gradient chain are deterministic (InstanceNorm statistics are a fixed-order reduction), only the weight-gradient
+    # sums use atomics.  Second step: the parameters already differ by that noise times Adam's sign-like update, and a
+    # ReLU mask that flips on a 4x12 map moves whole upstream tensors by ~1/sqrt(N) (tests/test_dropout_parity_gpu.py),
+    # so that comparison only guards against a lost or torn bucket (an O(1) error).
     for n, (o, c) in m._flat.offsets.items():
-        r = g0[o:o + c]
+        r = f0[o:o + c]
         if r.abs().max() == 0:
             continue
-        rel = ((g1[o:o + c] - r).norm() / r.norm()).item()
-        assert rel < 1e-5, (n, rel)
+        assert ((f1[o:o + c] - r).norm() / r.norm()).item() < 1e-5, n
+        assert ((g1[o:o + c] - g0[o:o + c]).norm() / g0[o:o + c].norm()).item() < 5e-2, n
     assert ((p1 - p0).abs().max()).item() < 5e-4      # two Adam steps of lr 1e-4: parameters can differ by at most ~2 lr
