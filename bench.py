@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""Headline benchmark: training samples/s of the encoder->decoder step (forward + backward + Adam) on synthetic
-score-image batches, BASELINE.json config C2: 6-layer d_model=256 image encoder + **bekern decoder, bs=32 per GPU,
-bf16 compute / fp32 master, 256x2048 images, T=512, V=6997, dropout ON.
+"""Headline benchmark: training samples/s of the encoder->decoder step (forward + backward + Adam) on synthetic batches.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--config c2]     (N>1: launched by torch.distributed.run, one rank per GPU)
 
-Rank 0 prints ONE JSON line with the driver's contract plus `roofline` (dominant kernel, live HIP-event timing
-against the MI355X peak) and `cpu_baseline` (the CPU oracle timed on this node's host cores on a bounded sample).
+Default workload = BASELINE.json configs[1] (C2): 6-layer d_model=256 image encoder + kern decoder, bs=32 per GPU, bf16 compute /
+fp32 master, 256x2048 images, T=512, V=6997, dropout ON, teacher-forcing noise ON.  Other BASELINE configs (one JSON line each
+is kept under profiles/): c1 tiny (d=128, L=2, 128x1024, T=128, fp32), c3 audio-only 195x512 log-STFT, c3mel audio-only
+80x1024 mel, c4 multimodal (image 256x2048 + audio 195x512, `concat` mixer, per-GPU batch 8 = global 64 on 8 GPUs).
+
+Rank 0 prints ONE JSON line with the driver's contract plus `roofline` (dominant kernel, live HIP-event timing against the
+MI355X peak) and `cpu_baseline` (the CPU oracle timed on this node's host cores on a bounded sample).
 """
 import argparse
 import json
@@ -23,10 +26,31 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA
 
+# name: (modalities, per-GPU batch, image HxW, audio HxW, T, layers, d_model, dtype)
+CONFIGS = {
+    "c1": dict(kind="image", batch=16, img=(128, 1024), aud=None, seq=128, layers=2, d=128, dtype="fp32",
+               what="C1: tiny 2-layer d_model=128 image-only OMR transformer, 16 samples"),
+    "c2": dict(kind="image", batch=32, img=(256, 2048), aud=None, seq=512, layers=6, d=256, dtype="bf16",
+               what="C2: image encoder (CNN) + 6-layer d_model=256 kern decoder"),
+    "c3": dict(kind="audio", batch=32, img=None, aud=(195, 512), seq=512, layers=6, d=256, dtype="bf16",
+               what="C3: audio-only branch, 195-bin log-STFT spectrogram encoder + 6-layer decoder"),
+    "c3mel": dict(kind="audio", batch=32, img=None, aud=(80, 1024), seq=512, layers=6, d=256, dtype="bf16",
+                  what="C3 (mel variant): audio-only branch, T x 80 mel-spectrogram encoder + 6-layer decoder"),
+    "c4": dict(kind="multimodal", batch=8, img=(256, 2048), aud=(195, 512), seq=512, layers=6, d=256, dtype="bf16",
+               what="C4: full multimodal (image + audio dual encoder, concat mixer, shared cross-attn decoder), global batch 64 on 8 GPUs"),
+}
 
-def fwd_flops_per_sample(H, W, T, S, d, L, V):
-    """encoder 122908*H*W + decoder L*(16Td^2 + 4Sd^2 + 4T^2d + 4TSd) + head 2TdV."""
-    return 122908.0 * H * W + L * (16.0 * T * d * d + 4.0 * S * d * d + 4.0 * T * T * d + 4.0 * T * S * d) + 2.0 * T * d * V
+
+def tokens_of(hw):
+    return ((hw[0] + 15) // 16) * ((hw[1] + 7) // 8)
+
+
+def fwd_flops_per_sample(c, V):
+    """encoder 122908*H*W per encoder + decoder L*(16Td^2 + 4Sd^2 + 4T^2d + 4TSd) + head 2TdV."""
+    enc = sum(122908.0 * hw[0] * hw[1] for hw in (c["img"], c["aud"]) if hw)
+    S = sum(tokens_of(hw) for hw in (c["img"], c["aud"]) if hw)
+    T, d, L = c["seq"], c["d"], c["layers"]
+    return enc + L * (16.0 * T * d * d + 4.0 * S * d * d + 4.0 * T * T * d + 4.0 * T * S * d) + 2.0 * T * d * V, S
 
 
 def main():
@@ -34,20 +58,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--height", type=int, default=256)
-    ap.add_argument("--width", type=int, default=2048)
-    ap.add_argument("--seq", type=int, default=512)
-    ap.add_argument("--layers", type=int, default=6)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (weak scaling)")
+    ap.add_argument("--layers", type=int, default=0)
+    ap.add_argument("--dtype", default="", choices=["", "bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    c = dict(CONFIGS[args.config])
+    if args.batch:
+        c["batch"] = args.batch
+    if args.layers:
+        c["layers"] = args.layers
+    if args.dtype:
+        c["dtype"] = args.dtype
 
     import torch.distributed as dist
     from omr_a2s_multimodal_transformer_amd import synthetic as syn
     from omr_a2s_multimodal_transformer_amd.config import ModelConfig
-    from omr_a2s_multimodal_transformer_amd.model import Transformer
+    from omr_a2s_multimodal_transformer_amd.model import MultimodalTransformer, Transformer
     from omr_a2s_multimodal_transformer_amd.runtime import seed_dropout
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -61,25 +90,35 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    V, H, W, T, B = syn.GRANDSTAFF_VOCAB, args.height, args.width, args.seq, args.batch
-    cfg = ModelConfig(d_model=256, nhead=4, ff_dim=256, num_layers=args.layers, compute_dtype=args.dtype)
+    V, T, B = syn.GRANDSTAFF_VOCAB, c["seq"], c["batch"]
+    cfg = ModelConfig(d_model=c["d"], nhead=4, ff_dim=c["d"], num_layers=c["layers"], compute_dtype=c["dtype"])
     # len(w2i) is the vocabulary size in the reference (model.py:101-103); ids as in grandstaff/vocabs/ar_w2i_kern.json
     w2i = {("<PAD>" if i == 0 else "<eos>" if i == syn.GRANDSTAFF_EOS else "<sos>" if i == syn.GRANDSTAFF_SOS else f"t{i}"): i for i in range(V)}
     i2w = {v: k for k, v in w2i.items()}
 
     torch.manual_seed(0)       # identical random-init weights on every rank (torch default init distributions)
-    random.seed(1234)          # Python RNG drives dropout placement / teacher-forcing noise: same stream on all ranks
-    model = Transformer(H, W, T, w2i, i2w, attn_window=-1, teacher_forcing_prob=0.2, config=cfg)
+    random.seed(1234)          # Python RNG drives dropout placement / modality drop / teacher-forcing noise: same stream on all ranks
+    sos, eos = syn.GRANDSTAFF_SOS, syn.GRANDSTAFF_EOS
+    if c["kind"] == "multimodal":
+        model = MultimodalTransformer(c["img"][0], c["img"][1], c["aud"][0], c["aud"][1], T, w2i, i2w, mixer_type="concat", attn_window=-1,
+                                      teacher_forcing_prob=0.2, teacher_forcing_modality_prob=0.2, config=cfg)      # train.py:76-95
+        xi, xli, y_in, y_out = syn.synthetic_unimodal_batch(B, c["img"][0], c["img"][1], T, V, sos, eos, seed=1234 + rank)
+        xa, xla, _, _ = syn.synthetic_unimodal_batch(B, c["aud"][0], c["aud"][1], T, V, sos, eos, seed=4321 + rank, pad_value=0.0)
+        batch = (xi.to(dev), xli.to(dev), xa.to(dev), xla.to(dev), y_in.pin_memory(), y_out.to(dev))
+        x1 = None
+    else:
+        hw = c["img"] if c["kind"] == "image" else c["aud"]
+        model = Transformer(hw[0], hw[1], T, w2i, i2w, attn_window=-1, teacher_forcing_prob=0.2, config=cfg)         # train.py:97-105
+        x, xl, y_in, y_out = syn.synthetic_unimodal_batch(B, hw[0], hw[1], T, V, sos, eos, seed=1234 + rank,
+                                                          pad_value=1.0 if c["kind"] == "image" else 0.0)
+        # token noise is host logic in the reference (model.py:152-160): y_in stays on the host, pinned
+        batch = (x.to(dev), xl.to(dev), y_in.pin_memory(), y_out.to(dev))
+        x1 = batch[0][:1]
     model.flatten_parameters(device=dev)
     model.train()
     seed_dropout(1234, rank)
     reducer = model.attach_reducer() if world > 1 else None
     opt = model.configure_optimizers()
-
-    x, xl, y_in, y_out = syn.synthetic_unimodal_batch(B, H, W, T, V, syn.GRANDSTAFF_SOS, syn.GRANDSTAFF_EOS, seed=1234 + rank)
-    x, xl, y_out = x.to(dev), xl.to(dev), y_out.to(dev)
-    y_in = y_in.pin_memory()    # token noise is host logic in the reference (model.py:152-160); stays on the host
-    batch = (x, xl, y_in, y_out)
 
     def step(i):
         opt.zero_grad()
@@ -112,27 +151,31 @@ def main():
         elapsed = float(t.item())
     final_loss = float(loss.detach())
 
-    S = ((H + 15) // 16) * ((W + 7) // 8)
-    step_flops = 3.0 * fwd_flops_per_sample(H, W, T, S, 256, args.layers, V)
+    fwd_flops, S = fwd_flops_per_sample(c, V)
+    step_flops = 3.0 * fwd_flops
     samples_per_s = B * world * args.steps / elapsed
+    peak_tf = MFMA_BF16_PEAK_TF if c["dtype"] == "bf16" else 157.3
 
     out = {
-        "metric": "training samples/sec (score+audio pairs)", "value": round(samples_per_s, 3), "unit": "samples/s",
+        "metric": "training samples/sec", "value": round(samples_per_s, 3), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"C2: image encoder (CNN) + {args.layers}-layer d_model=256 kern decoder, fwd+bwd+Adam, dropout on",
-                   "per_gpu_batch": B, "global_batch": B * world, "image": f"{H}x{W}x1", "seq_len": T, "memory_tokens": S, "vocab": V,
-                   "parallelism": f"dp{world}"},
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": c["dtype"], "data": "synthetic",
+        "config": {"workload": c["what"] + ", fwd+bwd+Adam, dropout on, teacher-forcing noise on; one sample = " +
+                   {"image": "one score image", "audio": "one spectrogram", "multimodal": "one score image + one spectrogram"}[c["kind"]] +
+                   " + its token sequence", "name": args.config, "per_gpu_batch": B, "global_batch": B * world,
+                   "image": None if not c["img"] else f"{c['img'][0]}x{c['img'][1]}x1", "audio": None if not c["aud"] else f"{c['aud'][0]}x{c['aud'][1]}x1",
+                   "seq_len": T, "memory_tokens": S, "layers": c["layers"], "d_model": c["d"], "vocab": V, "parallelism": f"dp{world}"},
         "final_loss": round(final_loss, 4),
         "step_tflops_algorithmic": round(step_flops * samples_per_s / 1e12, 2),
-        "mfma_frac_whole_step": round(step_flops * samples_per_s / world / 1e12 / MFMA_BF16_PEAK_TF, 4),
+        "mfma_frac_whole_step": round(step_flops * samples_per_s / world / 1e12 / peak_tf, 4),
     }
 
-    if rank == 0 and not args.no_roofline:
-        out["roofline"] = roofline_dominant_kernel(B, H, W, args.dtype)
-        out["decode"] = decode_rate(model, x[:1])
+    if rank == 0 and not args.no_roofline and args.config == "c2":
+        out["roofline"] = roofline_dominant_kernel(B, c["img"][0], c["img"][1], c["dtype"])
+    if rank == 0 and not args.no_roofline and x1 is not None:
+        out["decode"] = decode_rate(model, x1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(H, W, T, V, args.layers)
+        out["cpu_baseline"] = cpu_baseline(c, V)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -141,10 +184,11 @@ def main():
 
 
 def decode_rate(model, x1, steps=96):
-    """Greedy decode rate (bs=1, KV cache, host argmax readback per token like model.py:187) on one benchmark image.
+    """Greedy decode rate (bs=1, KV cache, host argmax readback per token like model.py:187) on one benchmark input.
     Random-init weights never emit <eos> reliably, so a fixed number of steps is timed."""
     from omr_a2s_multimodal_transformer_amd import kernels as K
     model.eval()
+    steps = min(steps, model.max_seq_len - 8)
     with torch.no_grad():
         mem = model.encode(x1)
         st = model.decoder.init_decode(mem)
@@ -158,7 +202,7 @@ def decode_rate(model, x1, steps=96):
             _ = int(idx.item())
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        # batched greedy: the same step over 32 same-sized images, one host readback per 8 steps
+        # batched greedy: the same step over 32 same-sized inputs, one host readback per 8 steps
         Bd = 32
         memb = mem.expand(Bd, -1, -1).contiguous()
         stb = model.decoder.init_decode(memb)
@@ -179,24 +223,31 @@ def decode_rate(model, x1, steps=96):
 
 
 def roofline_dominant_kernel(B, H, W, dtype):
-    """Dominant kernel of the step (profiles/): conv3x3_mfma on conv_blocks.1.conv2 (32->32 channels at full
-    resolution) -- the largest single contraction of the encoder.  Timed live with HIP events on the launch stream.
-    Algorithmic bytes per launch (SURVEY.md section 8d accounting: read the input once, write the output once, weights
-    negligible) = B*H*W*(Cin + Cout)*sizeof; algorithmic flops = 2*9*Cin*Cout*B*H*W."""
+    """Dominant kernel of the step (profiles/): conv3x3_mfma on conv_blocks.1.conv2 (32->32 channels at full resolution) --
+    the largest single contraction of the encoder -- IN THE INSTANTIATION THE TRAINING STEP RUNS: bias + ReLU + fused
+    MixDropout + fused InstanceNorm statistics of the output (template EPI = 1; the bias/ReLU-only EPI = 0 variant serves the
+    masked data gradient).  Timed live with HIP events on the launch stream.  Algorithmic bytes per launch (SURVEY.md section
+    8d accounting: read the input once, write the output once, weights and statistics negligible) = B*H*W*(Cin + Cout)*sizeof;
+    algorithmic flops = 2*9*Cin*Cout*B*H*W."""
     from omr_a2s_multimodal_transformer_amd import kernels as K
     dt = torch.bfloat16 if dtype == "bf16" else torch.float32
     cin = cout = 32
     x = torch.rand((B, H, W, cin), device="cuda").to(dt)
     w = (torch.rand((cout, 3, 3, cin), device="cuda") - 0.5).to(dt)
     bias = torch.zeros(cout, device="cuda")
+    ws, slots = K.conv_stat_ws(B, H, W, cout, x.device)
+
+    def launch():
+        return K.conv3x3(x, w, bias, relu=True, drop=(0.5, 1234, False), stat_mode=1, stat_ws=ws, stat_slots=slots)
+
     for _ in range(2):
-        K.conv3x3(x, w, bias, relu=True)
+        launch()
     torch.cuda.synchronize()
     n = 5
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
-        K.conv3x3(x, w, bias, relu=True)
+        launch()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
@@ -205,13 +256,13 @@ def roofline_dominant_kernel(B, H, W, dtype):
     gbs = nbytes / (ms * 1e-3) / 1e9
     traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same launch (profiles/)
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_dominant_kernel_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_dominant_kernel_pmc.json")) as f:
             if (B, H, W, dtype) == (32, 256, 2048, "bf16"):
                 traffic = json.load(f)["hbm_bytes_per_launch"]
     except Exception:
         pass
-    return {"kernel": "conv3x3_mfma_kernel (conv_blocks.1.conv2: 32->32 ch @ full resolution)", "bound": "hbm",
-            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+    return {"kernel": "conv3x3_mfma_kernel<EPI=1> (conv_blocks.1.conv2 forward: 32->32 ch @ full resolution, bias+ReLU+MixDropout+InstanceNorm statistics)",
+            "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
             "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": nbytes,
             "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1), "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)}
 
@@ -233,41 +284,71 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(H, W, T, V, layers):
-    """The CPU oracle (oracle/ref_cpu.py, fp32, plain torch ops = the reference's arithmetic) timed on this node's host
-    cores: forward + backward + Adam on a bounded sample (B=2 at the benchmark shapes; one timed step after a small
-    thread-pool warm-up)."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(c, V):
+    """The CPU oracle (oracle/ref_cpu.py, fp32, plain torch ops = the reference's arithmetic) timed on this node's host cores as
+    SURVEY.md section 8d prescribes: forward + backward + Adam at the benchmark shapes, B = 2, dropout ON (every site draws a
+    fresh Bernoulli mask with torch's CPU RNG, like the reference's nn.Dropout / nn.Dropout2d), 1 warm-up + 3 timed steps."""
     from oracle import ref_cpu as R
     from omr_a2s_multimodal_transformer_amd import synthetic as syn
     cores = usable_cores()
     torch.set_num_threads(cores)
-    Bc = 2
-    sd = syn.seeded_state_dict(syn.transformer_shapes(V, 256, 256, layers), 0, mode="torch_default")
+    Bc, T, L, d = 2, c["seq"], c["layers"], c["d"]
+    multimodal = c["kind"] == "multimodal"
+    shapes = syn.multimodal_shapes(V, "concat", d, d, L) if multimodal else syn.transformer_shapes(V, d, d, L)
+    sd = syn.seeded_state_dict(shapes, 0, mode="torch_default")
     for v in sd.values():
         v.requires_grad_(True)
     ps = list(sd.values())
     m = [torch.zeros_like(p) for p in ps]
     v2 = [torch.zeros_like(p) for p in ps]
-    cfg = R.OracleCfg(num_layers=layers)
+    cfg = R.OracleCfg(d_model=d, ff_dim=d, num_layers=L)
 
-    def one(step, x, xl, y_in, y_out, h, w):
+    def bernoulli_mask(site, kind, p, shape, channel):
+        if channel:
+            shape = tuple(shape[:2]) + (1,) * (len(shape) - 2)
+        return torch.empty(shape).bernoulli_(1.0 - p).div_(1.0 - p)
+
+    sos, eos = syn.GRANDSTAFF_SOS, syn.GRANDSTAFF_EOS
+    if multimodal:
+        xi, xli, y_in, y_out = syn.synthetic_unimodal_batch(Bc, c["img"][0], c["img"][1], T, V, sos, eos, seed=1)
+        xa, xla, _, _ = syn.synthetic_unimodal_batch(Bc, c["aud"][0], c["aud"][1], T, V, sos, eos, seed=2, pad_value=0.0)
+        fwd = lambda plan: R.multimodal_forward(sd, xi, xli, xa, xla, y_in, cfg, "concat", c["img"], c["aud"], "both", drop=plan)
+    else:
+        hw = c["img"] if c["kind"] == "image" else c["aud"]
+        x, xl, y_in, y_out = syn.synthetic_unimodal_batch(Bc, hw[0], hw[1], T, V, sos, eos, seed=1, pad_value=1.0 if c["kind"] == "image" else 0.0)
+        fwd = lambda plan: R.transformer_forward(sd, x, xl, y_in, cfg, hw[0], hw[1], drop=plan)
+
+    def one(step):
         for p in ps:
             p.grad = None
-        loss = R.ce_loss(R.transformer_forward(sd, x, xl, y_in, cfg, h, w), y_out)
+        loss = R.ce_loss(fwd(R.DropPlan(bernoulli_mask)), y_out)
         loss.backward()
         with torch.no_grad():
             R.adam_step(ps, [p.grad for p in ps], m, v2, step)
 
-    print(f"[bench] cpu_baseline: warm-up on {cores} threads", file=sys.stderr, flush=True)
-    one(1, *syn.synthetic_unimodal_batch(1, 32, 128, 16, V, syn.GRANDSTAFF_SOS, syn.GRANDSTAFF_EOS, seed=2), 32, 128)
-    batch = syn.synthetic_unimodal_batch(Bc, H, W, T, V, syn.GRANDSTAFF_SOS, syn.GRANDSTAFF_EOS, seed=1)
-    print("[bench] cpu_baseline: timed step", file=sys.stderr, flush=True)
-    t0 = time.perf_counter()
-    one(2, *batch, H, W)
-    dt = time.perf_counter() - t0
-    print(f"[bench] cpu_baseline: {dt:.1f} s", file=sys.stderr, flush=True)
-    return {"value": round(Bc / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"1 timed step of B={Bc} at the benchmark shapes ({H}x{W}, T={T}, L={layers}, V={V}), fp32, dropout off"}
+    random.seed(99)
+    print(f"[bench] cpu_baseline: warm-up step on {cores} threads", file=sys.stderr, flush=True)
+    one(1)
+    times = []
+    for s in range(3):
+        t0 = time.perf_counter()
+        one(2 + s)
+        times.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline: step {s} {times[-1]:.1f} s", file=sys.stderr, flush=True)
+    dt = sum(times) / len(times)
+    return {"value": round(Bc / dt, 4), "unit": "samples/s", "cores": cores, "cpu": cpu_model_name(), "kind": "port",
+            "sample": f"1 warm-up + 3 timed steps (mean) of B={Bc} at the benchmark shapes, fp32, dropout on, torch threads = {cores}",
+            "step_seconds": [round(t, 2) for t in times]}
 
 
 if __name__ == "__main__":
