@@ -186,39 +186,31 @@ def main():
 def decode_rate(model, x1, steps=96):
     """Greedy decode rate (bs=1, KV cache, host argmax readback per token like model.py:187) on one benchmark input.
     Random-init weights never emit <eos> reliably, so a fixed number of steps is timed."""
-    from omr_a2s_multimodal_transformer_amd import kernels as K
     model.eval()
-    steps = min(steps, model.max_seq_len - 8)
+    chunk = 16                                   # tokens per host call / readback (Transformer._greedy's default)
+    steps = max(chunk, min(steps, model.max_seq_len - chunk) // chunk * chunk)
+
+    def run(mem, B):
+        st = model.decoder.init_decode(mem)
+        tok = torch.full((B, 1), model.w2i["<sos>"], dtype=torch.int64, device=mem.device)
+        toks, _ = model.decoder.decode_tokens(tok, st, chunk)          # warm-up chunk
+        tok = toks[-1].view(B, 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps // chunk):
+            toks, _ = model.decoder.decode_tokens(tok, st, chunk)
+            _ = toks.cpu()                                              # the host needs the tokens to look for <eos>
+            tok = toks[-1].view(B, 1)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
     with torch.no_grad():
         mem = model.encode(x1)
-        st = model.decoder.init_decode(mem)
-        tok = torch.full((1, 1), model.w2i["<sos>"], dtype=torch.int64, device=mem.device)
-        for i in range(steps + 8):
-            if i == 8:
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-            idx, _ = K.argmax(model.decoder.decode_step(tok, st).contiguous())
-            tok = idx.view(1, 1)
-            _ = int(idx.item())
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        # batched greedy (SURVEY.md section 8f rank 1): the same step over 32 same-sized inputs, one host readback per 8 steps
-        Bd = 32
-        memb = mem.expand(Bd, -1, -1).contiguous()
-        stb = model.decoder.init_decode(memb)
-        tokb = torch.full((Bd, 1), model.w2i["<sos>"], dtype=torch.int64, device=mem.device)
-        for i in range(steps + 8):
-            if i == 8:
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-            idx, _ = K.argmax(model.decoder.decode_step(tokb, stb).contiguous())
-            tokb = idx.view(Bd, 1)
-            if i % 8 == 7:
-                _ = idx.cpu()
-        torch.cuda.synchronize()
-        dtb = time.perf_counter() - t1
+        dt = run(mem, 1)
+        Bd = 32                                   # batched greedy (SURVEY.md section 8f rank 1): 32 same-sized inputs in lock-step
+        dtb = run(mem.expand(Bd, -1, -1).contiguous(), Bd)
     model.train()
-    return {"tokens_per_s": round(steps / dt, 1), "steps": steps, "memory_tokens": int(mem.shape[1]), "kv_cache": True,
+    return {"tokens_per_s": round(steps / dt, 1), "steps": steps, "memory_tokens": int(mem.shape[1]), "kv_cache": True, "tokens_per_host_call": chunk,
             "batched_tokens_per_s": round(Bd * steps / dtb, 1), "batch": Bd}
 
 

@@ -90,7 +90,7 @@ int omr_topk_logprob(const float* x, int rows, int n, long ld, int k, long* idx_
  * the consumer adds an image's slots in index order -- no atomics.  workspace_bytes covers the slots plus the compact
  * [B][C][2] sums the backward apply reads; slots = omr_instnorm_slots(B, HW) for the stand-alone passes
  * (omr_instnorm_stats / omr_instnorm_bwd) or omr_conv3x3_stat_slots(B, Ho, Wo) when a conv epilogue is the producer
- * (the caller zero-fills that workspace: a conv launch may use fewer blocks per image than there are slots). */
+ * (a conv launch that uses fewer blocks per image than there are slots writes zeros into the rest: no clearing needed). */
 int omr_instnorm_slots(int B, long HW);
 long omr_instnorm_workspace_bytes(int B, int C, int slots);
 int omr_instnorm_stats(int dtype, const void* x, float* mean, float* rstd, int B, long HW, int C, float eps, void* workspace, void* stream);
@@ -167,6 +167,31 @@ int omr_attn_bwd(int dtype, const void* q, const void* k, const void* v, const v
                  long bsk, long bsv, long bso, long bsdo, long bsdq, long bsdk, long bsdv, int B, int H, int T, int S, int head_dim,
                  int causal, int window, const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p,
                  unsigned long long seed, void* stream);
+
+/* ---- KV-cached greedy decoding: one host call per run of tokens ------------------------------------------------------ */
+/* Reference: the autoregressive loop of Transformer.validation_step / get_pred_seq_and_pred_prob_seq (model.py:182-193,
+ * 247-260) -- embed the last token, run every decoder layer, project to the vocabulary, argmax, repeat.  omr_decode_steps
+ * runs n_steps positions t0 .. t0+n_steps-1 for B independent rows without returning to the caller in between: per position
+ * it appends the self-attention K|V to the cache, attends over the cached keys (banded by `window`, decoder.py:213-214) and
+ * over the cross-attention K|V projected once per input, and (out_tokens != NULL) writes the argmax token [step][B] (and its
+ * fp32 logit, out_top1, nullable) and feeds it to the next position through `tokens` (device int64 [B], updated in place).
+ * out_tokens == NULL: one position only, no token pick (beam search / late fusion choose the token themselves).
+ * last_logits (nullable): fp32 [B][ldv] logits of the last position.  All pointers are device pointers except `layer_w`.
+ * layer_w: HOST array [L][OMR_DECODE_LAYER_PTRS] of device pointers, per layer in this order (torch parameter names):
+ *   self_attn.in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, norm1.weight, norm1.bias,
+ *   multihead_attn.in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, norm2.weight, norm2.bias,
+ *   linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm3.weight, norm3.bias
+ * (matrices in `dtype`, biases / LayerNorm vectors fp32).  self_kv [L][B][max_len][2d]; cross_kv: layer l's K|V rows of
+ * sample b, key s at cross_kv + b*cross_bs + s*cross_ld + l*2d (elements; cross_bs = 0 shares one memory between rows). */
+#define OMR_DECODE_LAYER_PTRS 18
+typedef struct omr_decode_desc {
+    int dtype, B, L, d, nhead, ff, V, ldv, max_len, S, window, reserved;
+    const void* emb; const float* pe; const void* const* layer_w; const void* head_w; const float* head_b;
+    void* self_kv; const void* cross_kv; long cross_ld, cross_bs; void* ws; long ws_bytes;
+} omr_decode_desc;
+long omr_decode_workspace_bytes(const omr_decode_desc* desc);
+int omr_decode_steps(const omr_decode_desc* desc, long* tokens, int t0, int n_steps, long* out_tokens, float* out_top1, float* last_logits,
+                     void* stream);
 
 /* ---- loss ------------------------------------------------------------------------------------------------ */
 /* CrossEntropyLoss(ignore_index=pad) (model.py:109,166) on row-major logits [M][ldv]; acc2 = {sum, count} (fp64). */

@@ -147,7 +147,11 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? (CK == 16 ? 4 : 3) : 2)
                 const int n = n0 + (i >> 1);
                 double acc2 = 0.0;
                 for (int g = 0; g < NGRP; ++g) acc2 += (double)red[g * 2 * NT + i];
-                if (n < a.COUT) a.stat_ws[(((long)bimg * a.stat_slots + blockIdx.x) * a.COUT + n) * 2 + (i & 1)] = acc2;
+                if (n < a.COUT) {
+                    a.stat_ws[(((long)bimg * a.stat_slots + blockIdx.x) * a.COUT + n) * 2 + (i & 1)] = acc2;
+                    if (blockIdx.x == 0)          // slots no block of this launch owns read as zero: the caller need not clear the workspace
+                        for (int k = gridDim.x; k < a.stat_slots; ++k) a.stat_ws[(((long)bimg * a.stat_slots + k) * a.COUT + n) * 2 + (i & 1)] = 0.0;
+                }
             }
         }
     };

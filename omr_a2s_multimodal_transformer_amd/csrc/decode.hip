@@ -1,0 +1,103 @@
+// KV-cached greedy decoding as ONE host call per run of tokens (SURVEY.md section 8b `decode_step`, section 8f rank 1).
+// Reference loop: Transformer.validation_step / get_pred_seq_and_pred_prob_seq (src/transformer/model.py:182-193,247-260)
+// re-runs the whole decoder over the prefix for every token and reads the argmax back to the host each time.  Here the
+// host-side executor below issues the ~12 kernels per decoder layer of ONE new position back to back from C++ (no Python, no
+// per-kernel argument marshalling), appends that position's self-attention K|V to the cache by letting the K|V projection
+// GEMM write straight into its cache row, reads the cross-attention K|V that were projected once per input, and chains the
+// chosen token to the next step THROUGH DEVICE MEMORY (the embedding kernel of step t+1 reads the token the argmax kernel of
+// step t wrote), so n_steps tokens are produced without a single host synchronisation.  Same kernels and the same per-row
+// arithmetic as the training forward pass: the tokens equal the full re-run's (tests/test_model_gpu.py).
+#include "omr_common.h"
+#include "omr_hip.h"
+
+namespace {
+
+struct Ws {          // activation scratch of one step, carved out of the caller's workspace
+    char* x; char* q; char* o; char* proj; char* h; char* logits; float* logits32; float* lse; float* mean; float* rstd;
+};
+
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+size_t carve(const omr_decode_desc& d, char* base, Ws* w) {
+    const size_t es = d.dtype == OMR_BF16 ? 2 : 4, B = (size_t)d.B;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+    char* x = take(B * d.d * es); char* q = take(B * d.d * es); char* o = take(B * d.d * es); char* proj = take(B * d.d * es);
+    char* h = take(B * (size_t)d.ff * es); char* logits = take(B * (size_t)d.ldv * es);
+    float* l32 = (float*)take(B * (size_t)d.ldv * 4); float* lse = (float*)take(B * (size_t)d.nhead * 4);
+    float* mean = (float*)take(B * 4); float* rstd = (float*)take(B * 4);
+    if (w) *w = Ws{x, q, o, proj, h, logits, l32, lse, mean, rstd};
+    return off;
+}
+
+#define TRY(call) do { int rc__ = (call); if (rc__ != OMR_OK) return rc__; } while (0)
+
+}  // namespace
+
+extern "C" long omr_decode_workspace_bytes(const omr_decode_desc* d) {
+    if (!d || d->B <= 0 || d->d <= 0 || d->ff <= 0 || d->ldv < d->V) return OMR_ERR_ARG;
+    return (long)carve(*d, nullptr, nullptr);
+}
+
+extern "C" int omr_decode_steps(const omr_decode_desc* dp, long* tokens, int t0, int n_steps, long* out_tokens, float* out_top1,
+                                float* last_logits, void* stream) {
+    if (!dp || !tokens || n_steps < 1 || t0 < 0) return OMR_ERR_ARG;
+    const omr_decode_desc& d = *dp;
+    if (d.B <= 0 || d.L <= 0 || d.d <= 0 || d.d % d.nhead || d.V <= 0 || d.ldv < d.V || d.ldv % 8) return OMR_ERR_ARG;
+    if (t0 + n_steps > d.max_len) return OMR_ERR_ARG;                   // positional-encoding table / cache exhausted (decoder.py:31)
+    if (n_steps > 1 && !out_tokens) return OMR_ERR_ARG;                 // several steps need the token feedback
+    if (!d.emb || !d.pe || !d.layer_w || !d.head_w || !d.self_kv || !d.cross_kv || !d.ws) return OMR_ERR_ARG;
+    if (d.ws_bytes < (long)carve(d, nullptr, nullptr)) return OMR_ERR_ARG;
+    Ws w;
+    carve(d, (char*)d.ws, &w);
+    const int dt = d.dtype, B = d.B, dm = d.d, hd = dm / d.nhead;
+    const size_t es = dt == OMR_BF16 ? 2 : 4;
+    auto gemm = [&](const void* a, long lda, const void* wt, const float* bias, void* c, long ldc, int N, int K, int relu) {
+        return omr_gemm(dt, dt, 0, 0, B, N, K, a, lda, wt, K, c, ldc, bias, relu, 0, 1, nullptr, 0.f, 0, 0, 0, 0, 0, stream);
+    };
+    for (int s = 0; s < n_steps; ++s) {
+        const int t = t0 + s;
+        // embedding(tgt) + pe[t]  (decoder.py:124; T_len = 1 so every row of the batch takes the table row given)
+        TRY(omr_embed_pe_fwd(dt, tokens, d.emb, d.pe + (size_t)t * dm, w.x, B, 1, dm, d.V, stream));
+        const int lo = (d.window > 0 && t - d.window > 0) ? t - d.window : 0;      // banded causal mask = a key range (decoder.py:213-214)
+        for (int l = 0; l < d.L; ++l) {
+            const void* const* W = d.layer_w + (size_t)l * OMR_DECODE_LAYER_PTRS;
+            char* cache_l = (char*)d.self_kv + ((size_t)l * B * d.max_len) * 2 * dm * es;
+            // self-attention: q rows of the packed in_proj; the k|v rows go straight into position t of the cache
+            TRY(gemm(w.x, dm, W[0], (const float*)W[1], w.q, dm, dm, dm, 0));
+            TRY(gemm(w.x, dm, (const char*)W[0] + (size_t)dm * dm * es, (const float*)W[1] + dm, cache_l + (size_t)t * 2 * dm * es, (long)d.max_len * 2 * dm, 2 * dm, dm, 0));
+            const char* k0 = cache_l + (size_t)lo * 2 * dm * es;
+            TRY(omr_attn_fwd(dt, w.q, k0, k0 + (size_t)dm * es, w.o, w.lse, dm, 2 * dm, 2 * dm, dm, dm, (long)d.max_len * 2 * dm, (long)d.max_len * 2 * dm, dm,
+                             B, d.nhead, 1, t + 1 - lo, hd, 0, -1, nullptr, nullptr, nullptr, 0.f, 0, stream));
+            TRY(gemm(w.o, dm, W[2], (const float*)W[3], w.proj, dm, dm, dm, 0));
+            TRY(omr_add_layernorm_fwd(dt, w.proj, w.x, (const float*)W[4], (const float*)W[5], w.x, w.mean, w.rstd, B, dm, 1e-5f, 0.f, 0, stream));
+            // cross-attention over the memory K|V projected once (init): layer l's block of the [B][S][L*2d] buffer
+            TRY(gemm(w.x, dm, W[6], (const float*)W[7], w.q, dm, dm, dm, 0));
+            const char* ck = (const char*)d.cross_kv + (size_t)l * 2 * dm * es;
+            TRY(omr_attn_fwd(dt, w.q, ck, ck + (size_t)dm * es, w.o, w.lse, dm, d.cross_ld, d.cross_ld, dm, dm, d.cross_bs, d.cross_bs, dm,
+                             B, d.nhead, 1, d.S, hd, 0, -1, nullptr, nullptr, nullptr, 0.f, 0, stream));
+            TRY(gemm(w.o, dm, W[8], (const float*)W[9], w.proj, dm, dm, dm, 0));
+            TRY(omr_add_layernorm_fwd(dt, w.proj, w.x, (const float*)W[10], (const float*)W[11], w.x, w.mean, w.rstd, B, dm, 1e-5f, 0.f, 0, stream));
+            // feed-forward
+            TRY(gemm(w.x, dm, W[12], (const float*)W[13], w.h, d.ff, d.ff, dm, 1));
+            TRY(gemm(w.h, d.ff, W[14], (const float*)W[15], w.proj, dm, dm, d.ff, 0));
+            TRY(omr_add_layernorm_fwd(dt, w.proj, w.x, (const float*)W[16], (const float*)W[17], w.x, w.mean, w.rstd, B, dm, 1e-5f, 0.f, 0, stream));
+        }
+        // vocabulary head (Conv1d k=1, decoder.py:145-146) in the compute dtype like the training forward, then fp32 rows
+        TRY(gemm(w.x, dm, d.head_w, d.head_b, w.logits, d.ldv, d.V, dm, 0));
+        float* l32 = w.logits32;
+        if (dt == OMR_F32) l32 = (float*)w.logits;
+        else TRY(omr_cast(w.logits, dt, w.logits32, OMR_F32, (long)B * d.ldv, stream));
+        if (out_tokens) {
+            // greedy pick (model.py:187,253); the token is fed back to the next step through device memory
+            TRY(omr_argmax(l32, B, d.V, d.ldv, out_tokens + (size_t)s * B, out_top1 ? out_top1 + (size_t)s * B : nullptr, stream));
+            if (hipMemcpyAsync(tokens, out_tokens + (size_t)s * B, (size_t)B * sizeof(long), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+                return OMR_ERR_LAUNCH;
+        }
+        if (last_logits && s == n_steps - 1) {
+            if (hipMemcpyAsync(last_logits, l32, (size_t)B * d.ldv * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+                return OMR_ERR_LAUNCH;
+        }
+    }
+    return OMR_OK;
+}

@@ -66,32 +66,46 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const T* __restri
         out[i] = acc;
     }
 }
-// sums[b][c][2] = sum over the image's slots, in slot order (fixed): one thread per (b, c)
-__device__ __forceinline__ void slot_sums(const double* __restrict__ ws, long i, int C, int slots, double& s0, double& s1) {
-    const long b = i / C; const int c = (int)(i % C);
-    const double* p = ws + (b * slots * C + c) * 2;
-    s0 = 0.0; s1 = 0.0;
-    for (int k = 0; k < slots; ++k) { s0 += p[(long)k * C * 2]; s1 += p[(long)k * C * 2 + 1]; }
-}
-__global__ void instnorm_finalize_kernel(const double* __restrict__ ws, int slots, int C, float* __restrict__ mean, float* __restrict__ rstd, long n,
-                                         double inv_hw, float eps) {
-    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double s0, s1;
-    slot_sums(ws, i, C, slots, s0, s1);
-    double m = s0 * inv_hw;
-    double var = s1 * inv_hw - m * m;
-    if (var < 0) var = 0;
-    mean[i] = (float)m;
-    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
-}
-// compact[b][c][2] (the tail of the workspace) = slot sums: what the backward apply kernel reads
-__global__ void instnorm_collapse_kernel(const double* __restrict__ ws, int slots, int C, double* __restrict__ compact, long n) {
-    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double s0, s1;
-    slot_sums(ws, i, C, slots, s0, s1);
-    compact[2 * i] = s0; compact[2 * i + 1] = s1;
+// Stage 2.  One workgroup per image: value v = (channel, {sum | sum of squares}) of slot k lives at ws[b][k][v]; the 256 threads
+// are dealt out as (v, part) so that `parts` threads share a value, each adding the slots k = part, part + parts, ... in that
+// order, and the partial sums are then added in part order -- fixed order, no atomics, and no thread walks more than
+// slots / parts slots (a single thread per value was a 20-27 us latency chain per launch).
+// FINAL: mean / rstd; else: the compact sums [b][C][2] that the backward apply kernel reads.
+template <bool FINAL>
+__global__ __launch_bounds__(256) void instnorm_reduce_slots_kernel(const double* __restrict__ ws, int slots, int C, float* __restrict__ mean,
+                                                                    float* __restrict__ rstd, double* __restrict__ compact, double inv_hw, float eps) {
+    __shared__ double red[512];
+    const int b = blockIdx.x, NV = 2 * C, tid = threadIdx.x;
+    const double* base = ws + (long)b * slots * NV;
+    for (int v0 = 0; v0 < NV; v0 += 256) {                       // NV <= 256 in one round (C <= 128), two rounds for C = 256
+        const int nv = NV - v0 < 256 ? NV - v0 : 256;            // values of this round (a power of two for the encoder's widths)
+        const int parts = 256 / nv > 0 ? 256 / nv : 1;
+        const int v = tid % nv, part = tid / nv;
+        double acc = 0.0;
+        if (part < parts)
+            for (int k = part; k < slots; k += parts) acc += base[(long)k * NV + v0 + v];
+        __syncthreads();
+        if (part < parts) red[part * nv + v] = acc;
+        __syncthreads();
+        if (tid < nv) {
+            double s = 0.0;
+            for (int q = 0; q < parts; ++q) s += red[q * nv + tid];
+            red[256 + tid] = s;
+        }
+        __syncthreads();
+        if (FINAL) {
+            if (tid < nv / 2) {                                   // channel c = (v0 + 2 tid) / 2
+                const double m = red[256 + 2 * tid] * inv_hw;
+                double var = red[256 + 2 * tid + 1] * inv_hw - m * m;
+                if (var < 0) var = 0;
+                const long o = (long)b * C + v0 / 2 + tid;
+                mean[o] = (float)m;
+                rstd[o] = (float)(1.0 / sqrt(var + (double)eps));
+            }
+        } else if (tid < nv) {
+            compact[(long)b * NV + v0 + tid] = red[256 + tid];
+        }
+    }
 }
 
 // InstanceNorm backward.  With xhat = (x - mean) * rstd and g = dL/dxhat:
@@ -297,7 +311,7 @@ extern "C" int omr_instnorm_stats(int dtype, const void* x, float* mean, float* 
     DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_partial_kernel<T, false>), grid, 256, partial_lds_bytes(dtype), s, (const T*)x, (const T*)nullptr,
                                          (const float*)nullptr, (const float*)nullptr, (double*)workspace, HW, C, ppb));
     long n = (long)B * C;
-    hipLaunchKernelGGL(instnorm_finalize_kernel, cdiv(n, 256), 256, 0, s, (const double*)workspace, (int)grid.x, C, mean, rstd, n, 1.0 / (double)HW, eps);
+    hipLaunchKernelGGL((instnorm_reduce_slots_kernel<true>), B, 256, 0, s, (const double*)workspace, (int)grid.x, C, mean, rstd, (double*)nullptr, 1.0 / (double)HW, eps);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }
@@ -306,7 +320,7 @@ extern "C" int omr_instnorm_stats(int dtype, const void* x, float* mean, float* 
 extern "C" int omr_instnorm_finalize(const void* workspace, int slots, float* mean, float* rstd, int B, long HW, int C, float eps, void* stream) {
     if (B <= 0 || HW <= 0 || C <= 0 || slots < 1 || !workspace) return OMR_ERR_ARG;
     long n = (long)B * C;
-    hipLaunchKernelGGL(instnorm_finalize_kernel, cdiv(n, 256), 256, 0, (hipStream_t)stream, (const double*)workspace, slots, C, mean, rstd, n, 1.0 / (double)HW, eps);
+    hipLaunchKernelGGL((instnorm_reduce_slots_kernel<true>), B, 256, 0, (hipStream_t)stream, (const double*)workspace, slots, C, mean, rstd, (double*)nullptr, 1.0 / (double)HW, eps);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }
@@ -315,7 +329,7 @@ static int launch_bwd_apply(int dtype, const void* dxhat, const void* x, const f
                             int relu_mask, float relu_scale, double* ws, int slots, hipStream_t s) {
     double* compact = ws + (long)B * slots * C * 2;
     long n = (long)B * C;
-    hipLaunchKernelGGL(instnorm_collapse_kernel, cdiv(n, 256), 256, 0, s, (const double*)ws, slots, C, compact, n);
+    hipLaunchKernelGGL((instnorm_reduce_slots_kernel<false>), B, 256, 0, s, (const double*)ws, slots, C, (float*)nullptr, (float*)nullptr, compact, 0.0, 0.f);
     int ppb2 = 1024;
     dim3 grid2(cdiv(HW, ppb2), B);
     DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), grid2, 256, 0, s, (const T*)dxhat, (const T*)x, mean, rstd,

@@ -3,6 +3,7 @@ names as the reference's src/transformer/decoder.py (which wraps nn.TransformerD
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from typing import Optional, Tuple
 
@@ -11,6 +12,7 @@ import torch.nn as nn
 
 from . import functional as Fn
 from . import kernels as K
+from ._lib import cur_stream, dtype_code, lib, ptr, require_cuda
 from .runtime import next_seed
 
 
@@ -241,48 +243,31 @@ class Decoder(nn.Module):
             return None
         return dict(L=L, d=d, w=w, gw=gw, b=b, gb=gb)
 
-    # ---- KV-cached greedy decoding.  The reference re-runs the whole prefix every step
-    #      (model.py:184-193, O(T^3)); here each step projects ONE token, appends its self-attention K|V to a cache and
-    #      reads the cross-attention K|V that were projected once.  Same kernels, same per-row arithmetic order.
+    # ---- KV-cached greedy decoding (SURVEY.md section 8b `decode_step`, section 8f rank 1).  The reference re-runs the whole
+    #      prefix every step (model.py:184-193, O(T^3)) and reads the argmax back per token.  Here the native executor
+    #      omr_decode_steps (csrc/decode.hip) runs whole tokens from ONE host call each: it projects the new token, appends
+    #      its self-attention K|V to the cache, reads the cross-attention K|V projected once, and chains the chosen token to
+    #      the next position through device memory.  Same kernels, same per-row arithmetic order as the training forward.
     @torch.no_grad()
-    def init_decode(self, memory: torch.Tensor) -> dict:
+    def init_decode(self, memory: torch.Tensor) -> "DecodeState":
         emb_w = self.embedding.weight
         dt = torch.bfloat16 if getattr(emb_w, "omr_lowp", None) is not None else torch.float32
         if memory.dtype != dt:
             memory = K.cast(memory.contiguous(), dt)
-        memory = memory.contiguous()
-        layers = self.transformer_decoder.layers
-        d = emb_w.shape[1]
-        B = memory.shape[0]                   # the reference decodes bs = 1; the cache is batched
-        max_len = self.pos_1d.pe.shape[1]
-        return dict(t=0, dtype=dt, d=d,
-                    cross_kv=[l.multihead_attn.project_kv(memory) for l in layers],             # [B,S,2d] per layer, once
-                    self_kv=torch.empty((len(layers), B, max_len, 2 * d), dtype=dt, device=memory.device))
+        return DecodeState(self, memory.contiguous(), dt)
 
     @torch.no_grad()
-    def decode_step(self, token: torch.Tensor, st: dict) -> torch.Tensor:
+    def decode_step(self, token: torch.Tensor, st: "DecodeState") -> torch.Tensor:
         """token int64 [B,1] -> fp32 logits of the next position ([V] for B = 1, else [B,V]); advances the cache.  Every
         sample of the batch is at the same position t; rows are computed independently (same per-row arithmetic as bs = 1)."""
-        t, d, dt = st["t"], st["d"], st["dtype"]
-        if t >= self.pos_1d.pe.shape[1]:
-            raise RuntimeError("decode_step beyond max_seq_len (positional-encoding table exhausted)")
-        x = K.embed_pe(token.contiguous(), Fn.wt(self.embedding.weight, dt).view(-1, d), self.pos_1d.pe[0, t:t + 1])   # [1,1,d]
-        lo = max(0, t - self.attn_window) if self.attn_window > 0 else 0     # banded causal mask = a key range (decoder.py:213-214)
-        for li, layer in enumerate(self.transformer_decoder.layers):
-            sa = layer.self_attn
-            qkv = Fn.linear(x, sa.in_proj_weight, sa.in_proj_bias)                                # [B,1,3d]
-            st["self_kv"][li, :, t].copy_(qkv[:, 0, d:])
-            o = Fn.AttentionFn.apply(qkv[..., :d], st["self_kv"][li, :, lo:t + 1], sa.num_heads, False, -1, None, None, None, 0.0, 0)
-            x = Fn.AddLayerNormFn.apply(Fn.linear(o, sa.out_proj.weight, sa.out_proj.bias), x, layer.norm1.weight, layer.norm1.bias)
-            ca = layer.multihead_attn.cross_attention(x, st["cross_kv"][li], None, False)
-            x = Fn.AddLayerNormFn.apply(ca, x, layer.norm2.weight, layer.norm2.bias)
-            h = Fn.linear(x, layer.linear1.weight, layer.linear1.bias, relu=True)
-            x = Fn.AddLayerNormFn.apply(Fn.linear(h, layer.linear2.weight, layer.linear2.bias), x, layer.norm3.weight, layer.norm3.bias)
-        V = self.output_size
-        logits = Fn.linear(x, self.out_layer.weight, self.out_layer.bias, out_ld=K.round_up(V, 8))[:, 0]         # [B,V]
-        st["t"] = t + 1
-        logits = logits if logits.dtype == torch.float32 else K.cast(logits.contiguous(), torch.float32)
+        logits = st.step_logits(token)
         return logits[0] if logits.shape[0] == 1 else logits
+
+    @torch.no_grad()
+    def decode_tokens(self, token: torch.Tensor, st: "DecodeState", n_steps: int):
+        """Greedy-decode n_steps positions starting from `token` (int64 [B,1]) without a host round trip in between:
+        -> (tokens int64 [n_steps, B], their fp32 top-1 logits [n_steps, B]), both on the device (model.py:187,253)."""
+        return st.run(token, n_steps)
 
     def forward(self, tgt: torch.Tensor, memory: torch.Tensor, memory_len: Optional[torch.Tensor]) -> torch.Tensor:
         emb_w = self.embedding.weight
@@ -311,3 +296,113 @@ class Decoder(nn.Module):
         V = self.output_size
         logits = Fn.linear(x, self.out_layer.weight, self.out_layer.bias, out_ld=K.round_up(V, 8))  # [B,T,V], row pitch round_up(V,8)
         return logits.permute(0, 2, 1)  # [B, V, T] (decoder.py:145-146)
+
+
+class _DecodeDesc(ctypes.Structure):
+    """omr_decode_desc of include/omr_hip.h."""
+    _fields_ = [(n, ctypes.c_int) for n in ("dtype", "B", "L", "d", "nhead", "ff", "V", "ldv", "max_len", "S", "window", "reserved")] + [
+        ("emb", ctypes.c_void_p), ("pe", ctypes.c_void_p), ("layer_w", ctypes.c_void_p), ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p),
+        ("self_kv", ctypes.c_void_p), ("cross_kv", ctypes.c_void_p), ("cross_ld", ctypes.c_long), ("cross_bs", ctypes.c_long),
+        ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_long)]
+
+
+class DecodeState:
+    """Device state of one KV-cached decode: the cross-attention K|V of every layer projected ONCE into one [B, S, L*2d]
+    buffer, the self-attention K|V cache [L, B, max_len, 2d], the position t, and the descriptor omr_decode_steps reads.
+    Rows are independent: B same-sized inputs decode in lock-step (batched greedy), or B hypotheses share one memory (beam)."""
+
+    LAYER_PARAMS = ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight", "self_attn.out_proj.bias",
+                    "norm1.weight", "norm1.bias", "multihead_attn.in_proj_weight", "multihead_attn.in_proj_bias",
+                    "multihead_attn.out_proj.weight", "multihead_attn.out_proj.bias", "norm2.weight", "norm2.bias",
+                    "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias", "norm3.weight", "norm3.bias")
+
+    def __init__(self, dec: "Decoder", memory: torch.Tensor, dt: torch.dtype):
+        layers = dec.transformer_decoder.layers
+        self.dec, self.dtype, self.t = dec, dt, 0
+        self.L, self.d = len(layers), dec.embedding.weight.shape[1]
+        self.B, self.S = memory.shape[0], memory.shape[1]
+        self.max_len = dec.pos_1d.pe.shape[1]
+        self.V, self.ldv = dec.output_size, K.round_up(dec.output_size, 8)
+        L, d, dev = self.L, self.d, memory.device
+        # cross-attention K|V rows [d, 3d) of every layer's packed in_proj over the memory: one GEMM where the flat buffer
+        # holds the layers back to back (Decoder._cross_kv_pack), else one GEMM per layer into its column block
+        mem2 = memory.reshape(-1, d)
+        self.cross_kv = torch.empty((self.B, self.S, L * 2 * d), dtype=dt, device=dev)
+        kv2 = self.cross_kv.view(-1, L * 2 * d)
+        pack = dec._cross_kv_pack(dt)
+        if pack is not None:
+            K.gemm_row_groups(mem2, pack["w"], kv2, mem2.shape[0], L * 2 * d, d, bias=pack["b"], group=(2 * d, 3 * d, d, 1))
+        else:
+            for li, layer in enumerate(layers):
+                mha = layer.multihead_attn
+                w = Fn.wt(mha.in_proj_weight, dt)
+                K.gemm(mem2, w[d:], bias=mha.in_proj_bias.omr_phys[d:], out=kv2[:, li * 2 * d:(li + 1) * 2 * d])
+        self.cross_bs = self.S * L * 2 * d
+        self.self_kv = torch.empty((L, self.B, self.max_len, 2 * d), dtype=dt, device=dev)
+
+        def pointer(p):            # matrices in the compute dtype, vectors (biases, LayerNorm) fp32
+            return (Fn.wt(p, dt) if p.dim() >= 2 else p.omr_phys).data_ptr()
+
+        ptrs = []
+        for layer in layers:
+            named = dict(layer.named_parameters())
+            ptrs += [pointer(named[n]) for n in self.LAYER_PARAMS]
+        self._layer_w = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        self.pe = dec.pos_1d.pe[0].contiguous()
+        self.desc = _DecodeDesc()
+        self._bind()
+
+    def _bind(self) -> None:
+        """(Re)fill the descriptor after B / the buffers changed."""
+        dec, ds = self.dec, self.desc
+        ds.dtype, ds.B, ds.L, ds.d, ds.nhead = dtype_code(self.dtype), self.B, self.L, self.d, dec.transformer_decoder.layers[0].self_attn.num_heads
+        ds.ff, ds.V, ds.ldv, ds.max_len, ds.S = dec.transformer_decoder.layers[0].linear1.weight.shape[0], self.V, self.ldv, self.max_len, self.S
+        ds.window, ds.reserved = (dec.attn_window if dec.attn_window > 0 else -1), 0
+        ds.emb, ds.pe = Fn.wt(dec.embedding.weight, self.dtype).data_ptr(), self.pe.data_ptr()
+        ds.layer_w = ctypes.cast(self._layer_w, ctypes.c_void_p)
+        ds.head_w, ds.head_b = Fn.wt(dec.out_layer.weight, self.dtype).data_ptr(), dec.out_layer.bias.omr_phys.data_ptr()
+        ds.self_kv, ds.cross_kv, ds.cross_ld, ds.cross_bs = self.self_kv.data_ptr(), self.cross_kv.data_ptr(), self.L * 2 * self.d, self.cross_bs
+        ds.ws, ds.ws_bytes = 0, 0
+        nbytes = lib().query("omr_decode_workspace_bytes", ctypes.byref(ds))
+        if nbytes <= 0:
+            raise RuntimeError("libomr_hip: omr_decode_workspace_bytes rejected the decode descriptor")
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.self_kv.device)
+        ds.ws, ds.ws_bytes = self.ws.data_ptr(), nbytes
+        self.logits = torch.empty((self.B, self.ldv), dtype=torch.float32, device=self.self_kv.device)
+        self.tok = torch.empty(self.B, dtype=torch.int64, device=self.self_kv.device)
+
+    def share_memory_between(self, rows: int) -> None:
+        """Beam search: `rows` hypotheses over the ONE memory this state was initialised with (cross K|V batch stride 0)."""
+        assert self.B == 1 and self.t == 0
+        self.B, self.cross_bs = rows, 0
+        self.self_kv = torch.empty((self.L, rows, self.max_len, 2 * self.d), dtype=self.dtype, device=self.self_kv.device)
+        self._bind()
+
+    def reorder_rows(self, parents: torch.Tensor) -> None:
+        """Beam search: row i continues hypothesis parents[i] (re-gathers the self-attention cache rows)."""
+        self.self_kv = self.self_kv.index_select(1, parents)
+        self.desc.self_kv = self.self_kv.data_ptr()
+
+    def _check(self, token: torch.Tensor, n: int) -> None:
+        require_cuda(token)
+        if token.numel() != self.B or token.dtype != torch.int64:
+            raise RuntimeError(f"decode: expected {self.B} int64 tokens, got {tuple(token.shape)} {token.dtype}")
+        if self.t + n > self.max_len:
+            raise RuntimeError("decode_step beyond max_seq_len (positional-encoding table exhausted)")
+
+    def step_logits(self, token: torch.Tensor) -> torch.Tensor:
+        """One position, no token pick: fp32 logits [B, V] (a view of this state's buffer, valid until the next call)."""
+        self._check(token, 1)
+        self.tok.copy_(token.reshape(-1))
+        lib().call("omr_decode_steps", ctypes.byref(self.desc), ptr(self.tok), self.t, 1, None, None, ptr(self.logits), cur_stream())
+        self.t += 1
+        return self.logits[:, :self.V]
+
+    def run(self, token: torch.Tensor, n_steps: int):
+        self._check(token, n_steps)
+        self.tok.copy_(token.reshape(-1))
+        toks = torch.empty((n_steps, self.B), dtype=torch.int64, device=self.tok.device)
+        top1 = torch.empty((n_steps, self.B), dtype=torch.float32, device=self.tok.device)
+        lib().call("omr_decode_steps", ctypes.byref(self.desc), ptr(self.tok), self.t, n_steps, ptr(toks), ptr(top1), None, cur_stream())
+        self.t += n_steps
+        return toks, top1

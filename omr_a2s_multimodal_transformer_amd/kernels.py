@@ -195,9 +195,9 @@ def _stat_ws(B: int, C: int, slots: int, device, zero: bool) -> Tensor:
 
 
 def conv_stat_ws(B: int, Ho: int, Wo: int, C: int, device) -> Tuple[Tensor, int]:
-    """Zeroed workspace + slot count for a conv launch with a fused statistics epilogue (stat_mode 1 / 2)."""
+    """Workspace + slot count for a conv launch with a fused statistics epilogue (stat_mode 1 / 2); the launch writes every slot."""
     slots = lib().query("omr_conv3x3_stat_slots", B, Ho, Wo)
-    return _stat_ws(B, C, slots, device, True), slots
+    return _stat_ws(B, C, slots, device, False), slots
 
 
 def instnorm_stats(x: Tensor, eps: float = 1e-3) -> Tuple[Tensor, Tensor]:

@@ -142,24 +142,39 @@ class _Base(FlatModuleMixin, LightningModule):
         return d[token] if token in d else d[str(token)]
 
     @torch.no_grad()
-    def _greedy(self, memory: torch.Tensor, want_probs: bool = False, use_cache: bool = True):
+    def _greedy(self, memory: torch.Tensor, want_probs: bool = False, use_cache: bool = True, chunk: int = 16):
         """Autoregressive loop of validation_step / get_pred_seq_and_pred_prob_seq (model.py:182-193,247-260):
         bs=1, memory_len=None, argmax of the last-step logits, stop after <eos> or max_seq_len tokens.
-        use_cache=True runs the KV-cached step (Decoder.decode_step); use_cache=False re-runs the whole prefix each step
+        use_cache=True runs the KV-cached native executor (Decoder.decode_tokens: `chunk` tokens per host call, the chosen
+        token chained to the next position on the device; the host reads a chunk back at a time and cuts the sequence after
+        <eos>, so at most chunk - 1 positions are computed in vain); use_cache=False re-runs the whole prefix each step
         exactly like the reference.  Both give the same tokens (tests/test_model_gpu.py)."""
         sos = self.w2i[SOS_TOKEN]
         tok = torch.full((1, 1), sos, dtype=torch.int64, device=memory.device)
-        y_in = tok
         yhat: List[str] = []
         probs: List[float] = []
-        state = self.decoder.init_decode(memory) if use_cache else None
+        if use_cache:
+            state = self.decoder.init_decode(memory)
+            left = self.max_seq_len
+            while left > 0:
+                n = min(chunk, left)
+                toks, top1 = self.decoder.decode_tokens(tok, state, n)
+                toks_h, top1_h = toks[:, 0].cpu().tolist(), (top1[:, 0].cpu().tolist() if want_probs else None)      # one sync per chunk
+                for i, token in enumerate(toks_h):
+                    word = self._i2w(token)
+                    yhat.append(word)
+                    if want_probs:
+                        probs.append(float(top1_h[i]))
+                    if word == EOS_TOKEN:
+                        return yhat, probs
+                tok = toks[-1].view(1, 1)
+                left -= n
+            return yhat, probs
+        y_in = tok
         for _ in range(self.max_seq_len):
-            if use_cache:
-                last32 = self.decoder.decode_step(tok, state).contiguous()
-            else:
-                logits = self.decoder(tgt=y_in, memory=memory, memory_len=None)   # [1, V, t]
-                last = logits[0, :, -1]
-                last32 = K.cast(last.contiguous(), torch.float32) if last.dtype != torch.float32 else last.contiguous()
+            logits = self.decoder(tgt=y_in, memory=memory, memory_len=None)   # [1, V, t]
+            last = logits[0, :, -1]
+            last32 = K.cast(last.contiguous(), torch.float32) if last.dtype != torch.float32 else last.contiguous()
             idx, val = K.argmax(last32)
             token = int(idx.item())
             word = self._i2w(token)
@@ -168,9 +183,7 @@ class _Base(FlatModuleMixin, LightningModule):
                 probs.append(float(val.item()))
             if word == EOS_TOKEN:
                 break
-            tok = idx.view(1, 1)
-            if not use_cache:
-                y_in = torch.cat([y_in, tok], dim=1)
+            y_in = torch.cat([y_in, idx.view(1, 1)], dim=1)
         return yhat, probs
 
     @torch.no_grad()
@@ -183,33 +196,19 @@ class _Base(FlatModuleMixin, LightningModule):
         sos, eos = self.w2i[SOS_TOKEN], self.w2i[EOS_TOKEN]
         tok = torch.full((B, 1), sos, dtype=torch.int64, device=memory.device)
         state = self.decoder.init_decode(memory)
-        steps: List[torch.Tensor] = []
         done = [False] * B
         out: List[List[int]] = [[] for _ in range(B)]
-        consumed = 0
-
-        def drain():
-            nonlocal consumed
-            if consumed == len(steps):
-                return
-            host = torch.stack(steps[consumed:], dim=1).cpu().tolist()       # one device sync for the whole chunk
-            consumed = len(steps)
-            for b in range(B):
-                for t in host[b]:
+        left = self.max_seq_len
+        while left > 0 and not all(done):
+            n = min(sync_every, left)
+            toks, _ = self.decoder.decode_tokens(tok, state, n)      # n positions, tokens chained on the device
+            for row in toks.cpu().tolist():                           # one device sync for the whole chunk
+                for b, t in enumerate(row):
                     if not done[b]:
                         out[b].append(t)
                         done[b] = t == eos
-
-        for i in range(self.max_seq_len):
-            logits = self.decoder.decode_step(tok, state)
-            idx, _ = K.argmax((logits if logits.dim() == 2 else logits.view(1, -1)).contiguous())
-            steps.append(idx)
-            tok = idx.view(B, 1)
-            if (i + 1) % sync_every == 0:
-                drain()
-                if all(done):
-                    break
-        drain()
+            tok = toks[-1].view(B, 1)
+            left -= n
         return [[self._i2w(t) for t in seq] for seq in out]
 
     @torch.no_grad()
@@ -221,9 +220,7 @@ class _Base(FlatModuleMixin, LightningModule):
         sos, eos = self.w2i[SOS_TOKEN], self.w2i[EOS_TOKEN]
         dev = memory.device
         state = self.decoder.init_decode(memory)
-        state["cross_kv"] = [kv.expand(beam, -1, -1) for kv in state["cross_kv"]]      # every hypothesis reads the same memory K|V
-        L, _, max_len, w = state["self_kv"].shape
-        state["self_kv"] = torch.empty((L, beam, max_len, w), dtype=state["self_kv"].dtype, device=dev)
+        state.share_memory_between(beam)                     # every hypothesis reads the same memory K|V; own self-attention cache rows
         tok = torch.full((beam, 1), sos, dtype=torch.int64, device=dev)
         scores = [0.0] + [float("-inf")] * (beam - 1)       # only the first row is a real hypothesis before the first step
         seqs: List[List[int]] = [[] for _ in range(beam)]
@@ -250,7 +247,7 @@ class _Base(FlatModuleMixin, LightningModule):
             while len(parents) < beam:                                # pad with dead rows
                 parents.append(parents[0]); new_tok.append(new_tok[0]); new_scores.append(float("-inf")); new_seqs.append([])
             pidx = torch.tensor(parents, dtype=torch.int64, device=dev)
-            state["self_kv"] = state["self_kv"].index_select(1, pidx)
+            state.reorder_rows(pidx)
             tok = torch.tensor(new_tok, dtype=torch.int64, device=dev).view(beam, 1)
             scores, seqs = new_scores, new_seqs
         if exhausted and scores[0] > best_done[0]:

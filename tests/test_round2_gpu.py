@@ -157,3 +157,33 @@ def test_adam_skips_submodules_without_gradient_like_the_reference(golden):
         d = (ps[str(k)].detach().cpu() - sd0[str(k)]).double()
         np.testing.assert_allclose(float(d.abs().sum()), da, rtol=2e-2, err_msg=str(k))       # Adam's sign-like update amplifies tiny gradient differences
         np.testing.assert_allclose(d.flatten()[:8].numpy(), h, rtol=0.2, atol=2e-5, err_msg=str(k))
+
+
+@pytest.mark.parametrize("dtype,win,B", [("fp32", -1, 1), ("fp32", 3, 3), ("bf16", -1, 2)])
+def test_native_decode_runs_of_tokens_equal_single_steps(dtype, win, B):
+    """omr_decode_steps: n positions from ONE host call (token chained on the device) give exactly the tokens, top-1 logits
+    and cache contents of n single-position calls with the token picked by omr_argmax in between."""
+    from omr_a2s_multimodal_transformer_amd import kernels as K
+    from omr_a2s_multimodal_transformer_amd.model import Transformer
+    V = 30
+    w2i, i2w = syn.make_vocab(V)
+    m = Transformer(32, 96, 20, w2i, i2w, attn_window=win, config=ModelConfig(num_layers=3, compute_dtype=dtype)).eval()
+    load(m, syn.transformer_shapes(V, layers=3), 61)
+    m.flatten_parameters()
+    mem = m.encode(rnd((B, 1, 32, 96), 702).to(DEV))
+    tok0 = torch.full((B, 1), w2i["<sos>"], dtype=torch.int64, device=DEV)
+    st_run = m.decoder.init_decode(mem)
+    toks, top1 = m.decoder.decode_tokens(tok0, st_run, 9)
+    toks2, top2 = m.decoder.decode_tokens(toks[-1].view(B, 1), st_run, 4)           # a second run continues the same cache
+    st_one = m.decoder.init_decode(mem)
+    tok = tok0
+    for i in range(13):
+        logits = m.decoder.decode_step(tok, st_one)
+        idx, val = K.argmax(logits.view(B, -1).contiguous())
+        want_t, want_v = (toks[i], top1[i]) if i < 9 else (toks2[i - 9], top2[i - 9])
+        assert torch.equal(idx, want_t) and torch.equal(val, want_v), i
+        tok = idx.view(B, 1)
+    assert st_run.t == st_one.t == 13
+    assert torch.equal(st_run.self_kv[:, :, :13], st_one.self_kv[:, :, :13])
+    with pytest.raises(RuntimeError):
+        m.decoder.decode_tokens(tok, st_run, 8)                                      # 13 + 8 > max_seq_len 20: positional table exhausted
