@@ -158,6 +158,14 @@ int omr_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, flo
 int omr_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                  long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
                  const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed, void* stream);
+/* omr_attn_fwd for ONE block of at most 32 query rows (KV-cached decode: T = 1) with the keys split over workgroups of 256 keys
+ * (partial softmaxes merged by a second small kernel): a single query row would otherwise keep each (batch, head) on one
+ * workgroup walking all S keys.  No causal / block masks (a decode step sees every cached key), no dropout.
+ * split_ws: omr_attn_split_workspace_floats(...) floats of device scratch (0 = the shape needs no split). */
+long omr_attn_split_workspace_floats(int B, int H, int T, int S, int head_dim);
+int omr_attn_fwd_split(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
+                       long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, const float* key_bias,
+                       float* split_ws, long split_ws_floats, void* stream);
 /* Test / debug entry: the attention-probability dropout keep-mask (1 = kept) that omr_attn_fwd / omr_attn_bwd regenerate on
  * the fly for (seed, dropout_p), one byte per score, mask[B][H][T][S].  Lets a checker inject the very same mask into a CPU
  * restatement of nn.MultiheadAttention's dropout (tests/test_dropout_parity_gpu.py). */

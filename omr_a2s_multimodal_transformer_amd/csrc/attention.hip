@@ -28,6 +28,8 @@ struct AttnArgs {
     const int* blk_lq; const int* blk_lkv;             // [B] or null
     int B, H, T, S; float scale; int causal; int window;
     uint32_t drop_thresh; float drop_scale; uint64_t seed;
+    // single-query-block forward split over the keys (decode): blockIdx.x = split, partials [B][H][nsplit][T][HD + 2] floats
+    int nsplit, split_len; float* part;
     // backward only
     const void* dout; long lddo, bsdo;
     const float* delta;                                // [B][H][T]
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float bias_s[BST];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = SPLITW ? 0 : blockIdx.x * 128;      // SPLITW: blockIdx.x = key split
     const int q = q0 + (SPLITW ? 0 : wave * 32) + (lane & 31);
     const int kboff = SPLITW ? wave * BKV : 0;                  // this wave's keys inside the staged block
     const T* Q = (const T*)a.q + (long)b * a.bsq + h * HD;
@@ -188,6 +190,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     if (a.causal) {
         kv_end = min(a.S, q0 + 128);
         if (a.window > 0 && a.window < a.T) kv_beg = max(0, q0 - a.window) / BKV * BKV;
+    }
+    if constexpr (SPLITW) {
+        if (a.nsplit > 1) { kv_beg = blockIdx.x * a.split_len; kv_end = min(a.S, kv_beg + a.split_len); }
     }
     RowTile<T, HD, BST> kt, vt;
     float bias_r = 0.f;
@@ -335,6 +340,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 acc_o[d][r] = v;
             }
     }
+    if constexpr (SPLITW) {
+        if (a.nsplit > 1) {          // partial softmax of this key split: un-normalised O, running max (log2 domain) and sum
+            if (q < a.T) {
+                float* P = a.part + ((((long)b * a.H + h) * a.nsplit + blockIdx.x) * a.T + q) * (HD + 2);
+#pragma unroll
+                for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) P[d * 32 + acc_row(r, lane)] = acc_o[d][r];
+                if (hh == 0) { P[HD] = m_run; P[HD + 1] = l_tot; }
+            }
+            return;
+        }
+    }
     const float inv = l_tot > 0.f ? a.drop_scale / l_tot : 0.f;      // dropout rescale folded in (1 when p = 0)
     if (q < a.T) {
         T* O = (T*)a.o + (long)b * a.bso + (long)q * a.ldo + h * HD;
@@ -344,6 +362,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) O[d * 32 + acc_row(r, lane)] = from_f32<T>(acc_o[d][r] * inv);
         if (hh == 0 && a.lse) a.lse[((long)b * a.H + h) * a.T + q] = (l_tot > 0.f) ? (m_run + log2f(l_tot)) * LN2 : -INFINITY;
     }
+}
+
+// Merge of the key-split partials (same arithmetic as the in-kernel merge of the four waves): one 64-thread block per
+// (b, h, q), thread = output channel.
+template <typename T, int HD>
+__global__ __launch_bounds__(64) void attn_split_merge_kernel(AttnArgs a) {
+    const int q = blockIdx.x % a.T, bh = blockIdx.x / a.T, h = bh % a.H, b = bh / a.H, dch = threadIdx.x;
+    const float* P = a.part + (((long)bh * a.nsplit) * a.T + q) * (HD + 2);
+    const long pstride = (long)a.T * (HD + 2);
+    float mm = -INFINITY;
+    for (int j = 0; j < a.nsplit; ++j) mm = fmaxf(mm, P[j * pstride + HD]);
+    float l_tot = 0.f, o = 0.f;
+    for (int j = 0; j < a.nsplit; ++j) {
+        const float mj = P[j * pstride + HD];
+        const float wj = mj == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mj - mm);
+        l_tot += P[j * pstride + HD + 1] * wj;
+        if (dch < HD) o += P[j * pstride + dch] * wj;
+    }
+    const float inv = l_tot > 0.f ? a.drop_scale / l_tot : 0.f;
+    if (dch < HD) ((T*)a.o)[(long)b * a.bso + (long)q * a.ldo + h * HD + dch] = from_f32<T>(o * inv);
+    if (dch == 0 && a.lse) a.lse[((long)b * a.H + h) * a.T + q] = (l_tot > 0.f) ? (mm + log2f(l_tot)) * LN2 : -INFINITY;
 }
 
 // delta[b][h][q] = sum_d dO[q][h*HD+d] * O[q][h*HD+d]
@@ -661,8 +700,9 @@ __global__ void attn_dropout_mask_kernel(unsigned char* __restrict__ out, AttnAr
 }
 
 template <typename T, int HD> int run_fwd(const AttnArgs& a, hipStream_t s) {
-    if (a.T <= 32 && a.S > 64) {        // a single 32-row query block: split the keys over the waves instead
-        hipLaunchKernelGGL((attn_fwd_kernel<T, HD, true>), dim3(1, a.H, a.B), dim3(256), 0, s, a);
+    if (a.T <= 32 && a.S > 64) {        // a single 32-row query block: split the keys over the waves (and, with a workspace, over workgroups)
+        hipLaunchKernelGGL((attn_fwd_kernel<T, HD, true>), dim3(a.nsplit > 1 ? a.nsplit : 1, a.H, a.B), dim3(256), 0, s, a);
+        if (a.nsplit > 1) hipLaunchKernelGGL((attn_split_merge_kernel<T, HD>), dim3(a.B * a.H * a.T), dim3(64), 0, s, a);
         OMR_CHECK_LAUNCH();
         return OMR_OK;
     }
@@ -708,10 +748,40 @@ extern "C" int omr_attn_dropout_mask(unsigned char* mask, int B, int H, int T, i
     return OMR_OK;
 }
 
+static int attn_fwd_impl(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
+                         long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
+                         const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed,
+                         float* split_ws, long split_ws_floats, void* stream);
+
 extern "C" int omr_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                             long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
                             const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed,
                             void* stream) {
+    return attn_fwd_impl(dtype, q, k, v, o, lse, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, T, S, head_dim, causal, window, key_bias, blk_lq, blk_lkv,
+                         dropout_p, seed, nullptr, 0, stream);
+}
+
+/* floats of split workspace omr_attn_fwd_split wants for (B, H, T <= 32, S): partial softmaxes of the key splits */
+extern "C" long omr_attn_split_workspace_floats(int B, int H, int T, int S, int head_dim) {
+    if (B <= 0 || H <= 0 || T <= 0 || T > 32 || S <= 0) return 0;
+    const int nsplit = (S + 255) / 256;
+    return nsplit > 1 ? (long)B * H * nsplit * T * (head_dim + 2) : 0;
+}
+
+/* omr_attn_fwd for a single block of at most 32 query rows (KV-cached decode) with the KEYS split over workgroups of 256 keys
+ * each (flash-decoding): one query row otherwise keeps a (batch, head) pair on ONE workgroup that walks all S keys. */
+extern "C" int omr_attn_fwd_split(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
+                                  long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, const float* key_bias,
+                                  float* split_ws, long split_ws_floats, void* stream) {
+    if (T > 32) return OMR_ERR_ARG;
+    return attn_fwd_impl(dtype, q, k, v, o, lse, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, T, S, head_dim, 0, -1, key_bias, nullptr, nullptr, 0.f, 0,
+                         split_ws, split_ws_floats, stream);
+}
+
+static int attn_fwd_impl(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
+                         long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
+                         const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed,
+                         float* split_ws, long split_ws_floats, void* stream) {
     AttnArgs a = {};
     int rc = fill_common(a, B, H, T, S, head_dim, dropout_p, seed, causal, window, key_bias, blk_lq, blk_lkv);
     if (rc) return rc;
@@ -719,6 +789,12 @@ extern "C" int omr_attn_fwd(int dtype, const void* q, const void* k, const void*
     if (ldq % vec || ldk % vec || ldv % vec || ldo % 4) return OMR_ERR_ARG;
     a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.bsq = bsq; a.bsk = bsk; a.bsv = bsv; a.bso = bso;
+    a.nsplit = 1; a.split_len = 0; a.part = nullptr;
+    if (split_ws && T <= 32 && S > 256) {
+        const int nsplit = (S + 255) / 256;
+        if (split_ws_floats < (long)B * H * nsplit * T * (head_dim + 2)) return OMR_ERR_ARG;
+        a.nsplit = nsplit; a.split_len = 256; a.part = split_ws;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (dtype == OMR_BF16) return head_dim == 64 ? run_fwd<bf16, 64>(a, s) : run_fwd<bf16, 32>(a, s);
     if (dtype == OMR_F32) return head_dim == 64 ? run_fwd<float, 64>(a, s) : run_fwd<float, 32>(a, s);

@@ -14,6 +14,7 @@ namespace {
 
 struct Ws {          // activation scratch of one step, carved out of the caller's workspace
     char* x; char* q; char* o; char* proj; char* h; char* logits; float* logits32; float* lse; float* mean; float* rstd;
+    float* split; long split_floats;
 };
 
 inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
@@ -26,7 +27,10 @@ size_t carve(const omr_decode_desc& d, char* base, Ws* w) {
     char* h = take(B * (size_t)d.ff * es); char* logits = take(B * (size_t)d.ldv * es);
     float* l32 = (float*)take(B * (size_t)d.ldv * 4); float* lse = (float*)take(B * (size_t)d.nhead * 4);
     float* mean = (float*)take(B * 4); float* rstd = (float*)take(B * 4);
-    if (w) *w = Ws{x, q, o, proj, h, logits, l32, lse, mean, rstd};
+    const int smax = d.S > d.max_len ? d.S : d.max_len;                // key-split partials of the longer of the two attentions
+    const long sf = omr_attn_split_workspace_floats(d.B, d.nhead, 1, smax, d.d / d.nhead);
+    float* split = (float*)take((size_t)sf * 4);
+    if (w) *w = Ws{x, q, o, proj, h, logits, l32, lse, mean, rstd, split, sf};
     return off;
 }
 
@@ -67,15 +71,15 @@ extern "C" int omr_decode_steps(const omr_decode_desc* dp, long* tokens, int t0,
             TRY(gemm(w.x, dm, W[0], (const float*)W[1], w.q, dm, dm, dm, 0));
             TRY(gemm(w.x, dm, (const char*)W[0] + (size_t)dm * dm * es, (const float*)W[1] + dm, cache_l + (size_t)t * 2 * dm * es, (long)d.max_len * 2 * dm, 2 * dm, dm, 0));
             const char* k0 = cache_l + (size_t)lo * 2 * dm * es;
-            TRY(omr_attn_fwd(dt, w.q, k0, k0 + (size_t)dm * es, w.o, w.lse, dm, 2 * dm, 2 * dm, dm, dm, (long)d.max_len * 2 * dm, (long)d.max_len * 2 * dm, dm,
-                             B, d.nhead, 1, t + 1 - lo, hd, 0, -1, nullptr, nullptr, nullptr, 0.f, 0, stream));
+            TRY(omr_attn_fwd_split(dt, w.q, k0, k0 + (size_t)dm * es, w.o, w.lse, dm, 2 * dm, 2 * dm, dm, dm, (long)d.max_len * 2 * dm, (long)d.max_len * 2 * dm, dm,
+                                   B, d.nhead, 1, t + 1 - lo, hd, nullptr, w.split, w.split_floats, stream));
             TRY(gemm(w.o, dm, W[2], (const float*)W[3], w.proj, dm, dm, dm, 0));
             TRY(omr_add_layernorm_fwd(dt, w.proj, w.x, (const float*)W[4], (const float*)W[5], w.x, w.mean, w.rstd, B, dm, 1e-5f, 0.f, 0, stream));
             // cross-attention over the memory K|V projected once (init): layer l's block of the [B][S][L*2d] buffer
             TRY(gemm(w.x, dm, W[6], (const float*)W[7], w.q, dm, dm, dm, 0));
             const char* ck = (const char*)d.cross_kv + (size_t)l * 2 * dm * es;
-            TRY(omr_attn_fwd(dt, w.q, ck, ck + (size_t)dm * es, w.o, w.lse, dm, d.cross_ld, d.cross_ld, dm, dm, d.cross_bs, d.cross_bs, dm,
-                             B, d.nhead, 1, d.S, hd, 0, -1, nullptr, nullptr, nullptr, 0.f, 0, stream));
+            TRY(omr_attn_fwd_split(dt, w.q, ck, ck + (size_t)dm * es, w.o, w.lse, dm, d.cross_ld, d.cross_ld, dm, dm, d.cross_bs, d.cross_bs, dm,
+                                   B, d.nhead, 1, d.S, hd, nullptr, w.split, w.split_floats, stream));
             TRY(gemm(w.o, dm, W[8], (const float*)W[9], w.proj, dm, dm, dm, 0));
             TRY(omr_add_layernorm_fwd(dt, w.proj, w.x, (const float*)W[10], (const float*)W[11], w.x, w.mean, w.rstd, B, dm, 1e-5f, 0.f, 0, stream));
             // feed-forward
