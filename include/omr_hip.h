@@ -125,6 +125,18 @@ int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, int N, int K
              long ldc, const float* bias, int relu, int accumulate, int split_k, float* colsum_a, float drop_p,
              unsigned long long drop_seed, int row_group, int row_group_stride, int row_group_base, int row_group_operand, void* stream);
 
+/* Weight (and bias) gradients of SEVERAL linear layers in one launch: for each problem dw[n_out][n_in] += dy^T . x and
+ * db[n_out] += column sums of dy (db nullable), reducing over `rows`; dy [rows][ld_dy], x [rows][ld_x] in `dtype`, dw / db fp32
+ * accumulators (fp32 atomics: the buffers hold the running sums).  A linear's dW at d_model = 256 is too small to fill the
+ * chip on its own (aten::mm of the decoder layers / 1x1 point_convs, torch nn/modules/transformer.py:1158-1199,
+ * encoder.py:65-70): the backward pass collects them and launches them together.  row_group* (0 = off): dw rows / db
+ * entries are a row-group view as in omr_gemm (operand 3).  `problems` is a HOST array. */
+typedef struct omr_dw_problem {
+    const void* dy; const void* x; float* dw; float* db;
+    int rows, n_out, n_in, row_group; long ld_dy, ld_x, ld_dw; int row_group_stride, row_group_base;
+} omr_dw_problem;
+int omr_linear_wgrad_grouped(int dtype, int nprob, const omr_dw_problem* problems, void* stream);
+
 /* ---- convolutions (NHWC) --------------------------------------------------------------------------------- */
 /* nn.Conv2d 3x3 pad 1 (encoder.py:132-150) with fused bias + ReLU, optional fused InstanceNorm apply on the input
  * (in_mean/in_rstd [B][CIN]) and optional epilogue mask (y = mask>0 ? y*mask_scale : 0).  Weights [COUT][3][3][CIN].

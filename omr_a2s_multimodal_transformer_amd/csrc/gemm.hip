@@ -31,8 +31,8 @@ namespace {
 // operands -- hit the same L2 instead of pulling the panel over the fabric once per XCD.  Pure speed: any placement is
 // correct.  The grid is padded to whole rounds of 8 chunks; padded workgroups exit.
 struct TileId { int m, n, split; bool valid; };
-__device__ __forceinline__ TileId tile_of_block(const GemmArgs& g) {
-    const int L = blockIdx.x, slot = L >> 3;
+__device__ __forceinline__ TileId tile_of_block(const GemmArgs& g, int L) {      // L = block index inside this problem's grid
+    const int slot = L >> 3;
     const long J = ((long)(slot / g.chunk) * 8 + (L & 7)) * g.chunk + slot % g.chunk;
     TileId t;
     t.valid = J < g.total;
@@ -148,7 +148,7 @@ __device__ __forceinline__ typename Frag<T>::type load_frag(const T* lds, int ro
 // (one global round trip instead of four dependent ones -- these GEMMs are latency chains, not throughput problems), at
 // the price of 96 more staging registers.
 template <typename T, typename TC, bool TA, bool TB, bool FULLK>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int block_index) {
     typedef GemmCfg<T> Cfg;
     typedef typename Frag<T>::type F;
     constexpr bool SWAP = std::is_same<TC, bf16>::value;     // bf16 output: transposed accumulators + LDS-staged stores
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const TileId tile = tile_of_block(g);
+    const TileId tile = tile_of_block(g, block_index);
     if (!tile.valid) return;
     const int m0 = tile.m * BM, n0 = tile.n * BN;
     const int kbeg = tile.split * g.ksplit_len;
@@ -349,6 +349,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
+template <typename T, typename TC, bool TA, bool TB, bool FULLK>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    gemm_body<T, TC, TA, TB, FULLK>(g, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grouped weight-gradient GEMM: dW_p[n_out][n_in] += dY_p^T . X_p (+ db_p += column sums of dY_p) for up to DW_MAX linear
+// layers in ONE launch.  A decoder layer's dW products are 256 x 256 outputs reduced over 16 384 rows: launched one by one
+// they are a handful of workgroups each -- latency chains that leave most of the chip idle (50 launches, 4.2 ms per step at
+// C2).  Collected over the backward pass and launched together they are ~1 600 workgroups of 2 048-row reductions.  The
+// problem table travels in the kernel arguments (no descriptor buffer to keep alive); a workgroup finds its problem by its
+// block index (uniform scalar scan) and runs the ordinary transA/transB split-K body.
+struct DwProb {
+    const void* A; const void* B; float* C; float* colsum;
+    int M, N, K, ksplit_len; int lda, ldb, ldc, block0; int nt, mt, chunk, total; int grp, grp_stride, grp_base, pad;
+};
+constexpr int DW_MAX = 24;
+struct DwGroup { int nprob, pad; DwProb p[DW_MAX]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_dw_grouped_kernel(DwGroup grp) {
+    int pi = 0;
+    for (int i = 1; i < grp.nprob; ++i) pi = ((int)blockIdx.x >= grp.p[i].block0) ? i : pi;
+    const DwProb& q = grp.p[pi];
+    GemmArgs g;
+    g.A = q.A; g.B = q.B; g.C = q.C; g.bias = nullptr; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.ldc;
+    g.relu = 0; g.accum = 1; g.atomic = 1; g.ksplit_len = q.ksplit_len; g.colsum_a = q.colsum;
+    g.mt = q.mt; g.nt = q.nt; g.chunk = q.chunk; g.total = q.total;
+    g.drop_thresh = 0; g.drop_scale = 1.f; g.drop_seed = 0;
+    g.grp = q.grp; g.grp_stride = q.grp_stride; g.grp_base = q.grp_base; g.grp_operand = q.grp ? 3 : 0;
+    gemm_body<T, float, true, true, false>(g, (int)blockIdx.x - q.block0);
+}
+
 template <typename T, typename TC> int launch(GemmArgs g, int ta, int tb, int splits, hipStream_t s) {
     g.nt = cdiv(g.N, BN); g.mt = cdiv(g.M, BM);
     const bool fullk = !ta && splits == 1 && g.K <= 4 * GemmCfg<T>::BK;
@@ -403,4 +436,48 @@ extern "C" int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, i
         return launch<float, float>(g, transA, transB, splits, s);
     }
     return OMR_ERR_UNSUPPORTED;
+}
+
+/* Weight gradients of several linear layers in one launch (see gemm_dw_grouped_kernel).  rows = reduction length. */
+extern "C" int omr_linear_wgrad_grouped(int dtype, int nprob, const omr_dw_problem* probs, void* stream) {
+    if (nprob <= 0 || !probs) return OMR_ERR_ARG;
+    if (dtype != OMR_BF16 && dtype != OMR_F32) return OMR_ERR_UNSUPPORTED;
+    const int vec = dtype == OMR_BF16 ? 8 : 4, bk = dtype == OMR_BF16 ? 64 : 32;
+    // Split factor: all problems of the call together should put ~8 workgroups on every CU, no workgroup reducing fewer than
+    // 512 rows (below that the prologue / atomic epilogue dominate) -- chosen per problem from its own tile count.
+    long tiles_total = 0;
+    for (int i = 0; i < nprob; ++i) tiles_total += (long)cdiv(probs[i].n_out, BM) * cdiv(probs[i].n_in, BN);
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < nprob; base += DW_MAX) {
+        DwGroup grp;
+        grp.nprob = nprob - base < DW_MAX ? nprob - base : DW_MAX; grp.pad = 0;
+        int block0 = 0;
+        for (int i = 0; i < grp.nprob; ++i) {
+            const omr_dw_problem& q = probs[base + i];
+            if (!q.dy || !q.x || !q.dw || q.rows <= 0 || q.n_out <= 0 || q.n_in <= 0) return OMR_ERR_ARG;
+            if (q.ld_dy % vec || q.ld_x % vec || ((uintptr_t)q.dy & 15) || ((uintptr_t)q.x & 15)) return OMR_ERR_ARG;
+            if (q.row_group && (q.row_group % 128 || q.row_group_stride < q.row_group || q.row_group_base < 0)) return OMR_ERR_ARG;
+            DwProb& d = grp.p[i];
+            d.A = q.dy; d.B = q.x; d.C = q.dw; d.colsum = q.db;
+            d.M = q.n_out; d.N = q.n_in; d.K = q.rows; d.lda = (int)q.ld_dy; d.ldb = (int)q.ld_x; d.ldc = (int)q.ld_dw;
+            d.mt = cdiv(d.M, BM); d.nt = cdiv(d.N, BN);
+            long want = (2048L + tiles_total - 1) / tiles_total;            // splits so that the call totals ~2048 workgroups
+            long maxs = (q.rows + 511) / 512;
+            if (want > maxs) want = maxs;
+            if (want < 1) want = 1;
+            int len = cdiv(cdiv(d.K, (int)want), bk) * bk;
+            d.ksplit_len = len;
+            const int splits = cdiv(d.K, len);
+            d.total = d.nt * d.mt * splits;
+            d.chunk = splits > 1 ? d.nt * d.mt : d.nt;
+            const int nchunks = d.total / d.chunk;
+            d.block0 = block0;
+            block0 += cdiv(nchunks, 8) * 8 * d.chunk;
+            d.grp = q.row_group; d.grp_stride = q.row_group_stride; d.grp_base = q.row_group_base; d.pad = 0;
+        }
+        if (dtype == OMR_BF16) hipLaunchKernelGGL((gemm_dw_grouped_kernel<bf16>), dim3((unsigned)block0), dim3(256), 0, s, grp);
+        else hipLaunchKernelGGL((gemm_dw_grouped_kernel<float>), dim3((unsigned)block0), dim3(256), 0, s, grp);
+        OMR_CHECK_LAUNCH();
+    }
+    return OMR_OK;
 }

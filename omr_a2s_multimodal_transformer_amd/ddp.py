@@ -65,16 +65,23 @@ class GradReducer:
                                    "after every backward -- gradient accumulation across backwards is not supported")
             return
         self.done[i] = True
-        WgradStream.join()                     # weight gradients issued on the side stream belong to the bucket too
         b, e = self.buckets[i]
         view = self.flat.grad[b:e]
         if self.use_stream:
+            # Weight gradients collected / issued on the side stream belong to the bucket too: launch what is collected (one
+            # grouped GEMM) and let the COMMUNICATION stream wait for the side stream -- the compute stream goes straight on
+            # with the encoder's backward pass and only joins the side stream when the pass ends.
+            WgradStream.flush()
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
+                side = WgradStream._side.get(self.flat.device.index)
+                if side is not None:
+                    self.stream.wait_stream(side)
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
         else:
+            WgradStream.join()
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self) -> None:
@@ -109,6 +116,8 @@ class GradBoundary(Function):
             ctx.reducer._backwards += 1
             for i in ctx.bucket_ids:
                 ctx.reducer.reduce_bucket(i)
+        else:
+            WgradStream.flush()        # single GPU: the decoder's collected weight gradients start now, under the encoder's backward pass
         return (None, None) + tuple(gs)
 
 

@@ -172,9 +172,9 @@ class LinearFn(Function):
             g2 = g2.contiguous()
         if relu and mask_own:
             g2 = K.relu_bwd(g2.contiguous(), y2, own_scale)     # y2 is the stored (dropped) output: ReLU + dropout backward in one mask
-        M = g2.shape[0]
-        # dW and db in one pass, on the side stream (runtime.WgradStream): nothing in backward consumes them
-        WgradStream.run("linear", lambda: K.gemm(g2, x2, trans_a=True, trans_b=True, out=gw, accumulate=True, split_k=split_k_for(M, N, Kd), colsum_a=gb), g2, x2)
+        # dW and db in one pass (nothing in backward consumes them): collected and launched together with the other linear
+        # layers' at the next flush point, on the side stream (runtime.WgradStream.defer_linear)
+        WgradStream.defer_linear(g2, x2, gw, gb)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.gemm(g2, w, trans_b=True).view(xshape)
@@ -362,8 +362,7 @@ class FusedCrossKVFn(Function):
             elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
                 dst.copy_(g)
         g2 = buf.view(Rm, L * 2 * d)
-        WgradStream.run("cross_kv", lambda: K.gemm_row_groups(g2, mem2, pack["gw"], L * 2 * d, d, Rm, trans_a=True, trans_b=True, accumulate=True,
-                                                  split_k=split_k_for(Rm, L * 2 * d, d), colsum_a=pack["gb"], group=(2 * d, 3 * d, d, 3)), g2, mem2)
+        WgradStream.defer_linear(g2, mem2, pack["gw"], pack["gb"], group=(2 * d, 3 * d, d))
         dmem = None
         if ctx.needs_input_grad[0]:
             dmem = torch.empty((Rm, d), dtype=mem2.dtype, device=mem2.device)

@@ -6,6 +6,7 @@ row-major with unit inner stride (row stride may exceed the width).
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from typing import Optional, Tuple
 
@@ -66,6 +67,39 @@ def gemm_row_groups(a: Tensor, b: Tensor, out: Tensor, M: int, N: int, Kd: int, 
     lib().call("omr_gemm", dtype_code(a.dtype), dtype_code(out.dtype), int(trans_a), int(trans_b), M, N, Kd, ptr(a), a.stride(0), ptr(b), b.stride(0),
                ptr(out), out.stride(0), ptr(bias), 0, int(accumulate), split_k, ptr(colsum_a), 0.0, 0, grp, stride, base, operand, cur_stream())
     return out
+
+
+class _DwProblem(ctypes.Structure):
+    """omr_dw_problem of include/omr_hip.h."""
+    _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("db", ctypes.c_void_p),
+                ("rows", ctypes.c_int), ("n_out", ctypes.c_int), ("n_in", ctypes.c_int), ("row_group", ctypes.c_int),
+                ("ld_dy", ctypes.c_long), ("ld_x", ctypes.c_long), ("ld_dw", ctypes.c_long),
+                ("row_group_stride", ctypes.c_int), ("row_group_base", ctypes.c_int)]
+
+
+def linear_wgrad_grouped(problems) -> None:
+    """Weight / bias gradients of several linear layers in ONE launch (omr_linear_wgrad_grouped).  problems: sequence of
+    (dy [rows, n_out], x [rows, n_in], dw fp32 [n_out(+), n_in] accumulated in place, db fp32 or None, group) with
+    group = None or (rows per group, physical group stride, first row inside a group) for a row-group view of dw / db."""
+    if not problems:
+        return
+    arr = (_DwProblem * len(problems))()
+    dt = problems[0][0].dtype
+    for q, (dy, x, dw, db, group) in zip(arr, problems):
+        require_cuda(dy, x, dw, db)
+        assert dy.dtype == x.dtype == dt and dw.dtype == torch.float32 and dy.dim() == x.dim() == dw.dim() == 2
+        assert dy.stride(1) == x.stride(1) == dw.stride(1) == 1 and dy.shape[0] == x.shape[0]
+        rows, n_out = dy.shape
+        n_in = x.shape[1]
+        grp, gstride, gbase = group if group is not None else (0, 0, 0)
+        phys_rows = n_out if not grp else (n_out // grp - 1) * gstride + gbase + grp
+        assert dw.shape[1] == n_in and dw.shape[0] >= phys_rows, (tuple(dw.shape), n_out, n_in)
+        if db is not None:
+            assert db.dtype == torch.float32 and db.is_contiguous() and db.numel() >= phys_rows
+        q.dy, q.x, q.dw, q.db = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
+        q.rows, q.n_out, q.n_in, q.row_group = rows, n_out, n_in, grp
+        q.ld_dy, q.ld_x, q.ld_dw, q.row_group_stride, q.row_group_base = dy.stride(0), x.stride(0), dw.stride(0), gstride, gbase
+    lib().call("omr_linear_wgrad_grouped", dtype_code(dt), len(problems), ctypes.byref(arr), cur_stream())
 
 
 def cast(x: Tensor, dtype: torch.dtype, out: Optional[Tensor] = None) -> Tensor:

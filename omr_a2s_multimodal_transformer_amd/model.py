@@ -128,9 +128,9 @@ class _Base(FlatModuleMixin, LightningModule):
     def _boundary(self, *mems: torch.Tensor):
         """Memory hand-off encoder(s) -> [mixer ->] decoder: when backward gets here every gradient of the decoder-side bucket
         is final."""
-        if self._reducer is None or not torch.is_grad_enabled():
+        if not torch.is_grad_enabled():
             return mems[0] if len(mems) == 1 else mems
-        from .ddp import GradBoundary
+        from .ddp import GradBoundary      # without a reducer the node only starts the decoder's collected weight gradients (runtime.WgradStream)
         return GradBoundary.apply(self._reducer, (1,), *mems)
 
     def configure_optimizers(self):

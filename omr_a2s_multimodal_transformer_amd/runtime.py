@@ -55,9 +55,9 @@ class WgradStream:
     under the data-gradient kernels of the main stream instead of between them.  Ordering: the side stream waits for the main
     stream's position at every hand-off (its inputs were produced there); the main stream waits for the side stream once,
     when the backward pass ends (autograd engine callback), and before anything else that touches the flat gradient buffer
-    (all-reduce buckets, zero_grad, Adam -- they call join()).  Tensors read on the side stream are recorded on it so the
-    caching allocator does not hand their memory out early, AND a reference to each of them is held until the side-stream
-    kernel that reads it has finished: autograd accumulates a second incoming gradient IN PLACE into a buffer nobody else
+    (all-reduce buckets, zero_grad, Adam -- they call join()).  A reference to every tensor read on the side stream is held
+    until the side-stream kernel that reads it has finished, for two reasons: the caching allocator must not hand the memory
+    out early, and autograd accumulates a second incoming gradient IN PLACE into a buffer nobody else
     references (a residual add hands the same gradient tensor to both of its inputs), and that in-place add on the main
     stream would otherwise race with the weight-gradient GEMM still reading the tensor on the side stream (seen as 4-30 %
     errors in the point_conv weight gradients in front of the encoder's residual adds when the side stream lags)."""
@@ -67,6 +67,9 @@ class WgradStream:
     _side = {}
     _pending = {}          # device index -> the stream that has to wait
     _hold = []             # (event recorded behind the side-stream kernel, the tensors it reads)
+    _deferred = []         # weight-gradient problems of linear layers collected for one grouped launch (defer_linear)
+    _callback = False      # the end-of-backward engine callback (join) is queued
+    defer = True           # collect the linear layers' weight gradients instead of launching them one by one
 
     @classmethod
     def _release_finished(cls, everything: bool = False) -> None:
@@ -92,20 +95,52 @@ class WgradStream:
             fn()
             ev = torch.cuda.Event()
             ev.record(side)
-        for t in tensors:
-            t.record_stream(side)
+        # no Tensor.record_stream: the references held below keep the operands' memory from being reused until the side-stream
+        # kernel has finished (or the main stream has joined the side stream), without the allocator's per-block event traffic
         cls._release_finished()
         cls._hold.append((ev, tensors))
-        first = not cls._pending
         cls._pending[dev] = main
-        if first:
-            try:
-                torch.autograd.Variable._execution_engine.queue_callback(cls.join)
-            except RuntimeError:      # not inside a backward pass (direct call from a test): order it right away
-                cls.join()
+        cls._at_end_of_backward()
+
+    @classmethod
+    def _at_end_of_backward(cls) -> None:
+        """Queue join() to run when the backward pass ends (once per pass)."""
+        if cls._callback:
+            return
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(cls.join)
+            cls._callback = True
+        except RuntimeError:          # not inside a backward pass (direct call from a test): order it right away
+            cls.join()
+
+    @classmethod
+    def defer_linear(cls, dy2d, x2d, dw2d, db, group=None) -> None:
+        """dW = dY^T X (+ db) of a linear layer.  At d_model = 256 one such product is a handful of workgroups -- a latency
+        chain that cannot fill the chip -- so the products of a backward pass are collected here and launched TOGETHER
+        (omr_linear_wgrad_grouped: ~2 000 workgroups in one grid) when the pass reaches a flush point: a gradient-bucket
+        boundary (ddp.GradBoundary) or its end.  The queue holds the operands alive until then."""
+        from . import kernels as K
+        if not (cls.defer and dy2d.is_cuda):
+            cls.run("linear", lambda: K.linear_wgrad_grouped([(dy2d, x2d, dw2d, db, group)]), dy2d, x2d)
+            return
+        cls._deferred.append((dy2d, x2d, dw2d, db, group))
+        cls._at_end_of_backward()
+
+    @classmethod
+    def flush(cls) -> None:
+        """Launch what defer_linear collected (on the side stream when enabled for "linear")."""
+        if not cls._deferred:
+            return
+        from . import kernels as K
+        probs, cls._deferred = cls._deferred, []
+        for dt in {p[0].dtype for p in probs}:
+            same = [p for p in probs if p[0].dtype == dt]
+            cls.run("linear", lambda: K.linear_wgrad_grouped(same), *[t for p in same for t in p[:2]])
 
     @classmethod
     def join(cls) -> None:
+        cls._callback = False
+        cls.flush()
         for dev, main in list(cls._pending.items()):
             main.wait_stream(cls._side[dev])
         cls._pending.clear()

@@ -159,6 +159,43 @@ def test_adam_skips_submodules_without_gradient_like_the_reference(golden):
         np.testing.assert_allclose(d.flatten()[:8].numpy(), h, rtol=0.2, atol=2e-5, err_msg=str(k))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_grouped_linear_weight_gradients_match_torch(dtype):
+    """omr_linear_wgrad_grouped: many (dY, X) pairs of different shapes in one launch, accumulated into fp32 buffers that
+    already hold values; ragged sizes, a strided dY (logit rows with a padded pitch), a row-group view of dW / db, and more
+    problems than one kernel-argument table holds."""
+    from omr_a2s_multimodal_transformer_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    shapes = [(1000, 256, 256), (77, 768, 256), (4096, 128, 128), (513, 50, 256), (2048, 256, 128)] * 6      # 30 problems (> 24)
+    probs, refs = [], []
+    for i, (rows, n_out, n_in) in enumerate(shapes):
+        ld = (n_out + 7) // 8 * 8 + (8 if i % 2 else 0)
+        dybuf = (torch.randn((rows, ld), generator=g) * 0.5).to(dtype)
+        x = torch.randn((rows, n_in), generator=g).to(dtype)
+        dw0, db0 = torch.randn((n_out, n_in), generator=g), torch.randn(n_out, generator=g)
+        dy = dybuf[:, :n_out]
+        refs.append((dw0.double() + dy.double().t() @ x.double(), db0.double() + dy.double().sum(0)))
+        probs.append((dybuf.to(DEV)[:, :n_out], x.to(DEV), dw0.to(DEV), db0.to(DEV) if i % 3 else None, None))
+    # row-group view: two groups of 128 rows inside a [2 * 384, 64] block (rows [128, 256) of each 384-row group)
+    dy, x = torch.randn((640, 256), generator=g).to(dtype), torch.randn((640, 64), generator=g).to(dtype)
+    blk, bb = torch.randn((768, 64), generator=g), torch.randn(768, generator=g)
+    want_w, want_b = blk.double().clone(), bb.double().clone()
+    full_w, full_b = dy.double().t() @ x.double(), dy.double().sum(0)
+    for grp in range(2):
+        want_w[grp * 384 + 128: grp * 384 + 256] += full_w[grp * 128:(grp + 1) * 128]
+        want_b[grp * 384 + 128: grp * 384 + 256] += full_b[grp * 128:(grp + 1) * 128]
+    probs.append((dy.to(DEV), x.to(DEV), blk.to(DEV), bb.to(DEV), (128, 384, 128)))
+    K.linear_wgrad_grouped(probs)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2        # bf16 inputs were rounded before the fp64 reference was formed: only accumulation order differs
+    tol = 1e-4 if dtype == torch.float32 else 1e-3
+    for (dy_, x_, dw, db, _), (rw, rb) in zip(probs[:-1], refs):
+        assert ((dw.double().cpu() - rw).norm() / rw.norm()).item() < tol
+        if db is not None:
+            assert ((db.double().cpu() - rb).norm() / rb.norm()).item() < tol
+    assert ((probs[-1][2].double().cpu() - want_w).norm() / want_w.norm()).item() < tol
+    assert ((probs[-1][3].double().cpu() - want_b).norm() / want_b.norm()).item() < tol
+
+
 @pytest.mark.parametrize("dtype,win,B", [("fp32", -1, 1), ("fp32", 3, 3), ("bf16", -1, 2)])
 def test_native_decode_runs_of_tokens_equal_single_steps(dtype, win, B):
     """omr_decode_steps: n positions from ONE host call (token chained on the device) give exactly the tokens, top-1 logits
