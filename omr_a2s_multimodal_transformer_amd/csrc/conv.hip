@@ -690,7 +690,7 @@ extern "C" int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const fl
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.mean = in_mean; a.rstd = in_rstd; a.mask = out_mask; a.mask_scale = mask_scale;
     a.B = B; a.Hr = H; a.Wr = W; a.CIN = CIN; a.Ho = Ho; a.Wo = Wo; a.COUT = COUT;
     a.sh = stride_h; a.sw = stride_w; a.dh = dil_h; a.dw = dil_w; a.relu = relu; a.tiles_w = a.tiles_h = 0;
-    a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_scale = 1.f / (1.f - drop_p); a.drop_seed = drop_seed;
+    a.drop_thresh = OMR_DROP_THRESH16(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.drop_seed = drop_seed;
     a.drop_channel = drop_channel_mode;
     a.stat_mode = stat_mode; a.stat_ws = stat_ws; a.stat_x = stat_x; a.stat_mean = stat_mean; a.stat_rstd = stat_rstd; a.stat_slots = stat_slots;
     if (dtype == OMR_BF16) return omr_conv3x3_dispatch_bf16(a, s);

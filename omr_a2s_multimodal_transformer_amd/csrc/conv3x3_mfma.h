@@ -336,14 +336,18 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? (CK == 16 ? 4 : 3) : 2)
             const long o = ((long)oh * a.Wo + ow) * a.COUT + n;
             if constexpr (EPI == 1) {
                 if (a.drop_thresh) {   // MixDropout after the ReLU, keyed exactly like omr_dropout (flat NHWC index / (image, channel))
-                    // drop_keep() of the VEC consecutive indices base .. base + VEC - 1 with the index folding hoisted: base is a
-                    // multiple of VEC (COUT % VEC == 0), so (base + e) == (base ^ e) in the low word and the high word is shared
-                    const uint64_t base = a.drop_channel ? (uint64_t)b * a.COUT + n : img_base + (uint64_t)o;
-                    const uint32_t h0 = (uint32_t)base ^ (uint32_t)(base >> 32) * 0x27D4EB2Fu;
+                    // drop_keep() of the VEC consecutive indices base .. base + VEC - 1: ONE hash per element pair (16 random bits
+                    // each), with the index folding hoisted -- base is a multiple of VEC (COUT % VEC == 0), so the pair indices are
+                    // (base >> 1) ^ e in the low word and share the high word
+                    const uint64_t pbase = (a.drop_channel ? (uint64_t)b * a.COUT + n : img_base + (uint64_t)o) >> 1;
+                    const uint32_t h0 = (uint32_t)pbase ^ (uint32_t)(pbase >> 32) * 0x27D4EB2Fu;
                     const uint32_t slo = (uint32_t)a.drop_seed, shi = (uint32_t)(a.drop_seed >> 32);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e)
-                        v[e] = hash32(slo, shi, h0 ^ (uint32_t)e) >= a.drop_thresh ? from_f32<T>(to_f32(v[e]) * a.drop_scale) : from_f32<T>(0.f);
+                    for (int e = 0; e < VEC / 2; ++e) {
+                        const uint32_t hsh = hash32(slo, shi, h0 ^ (uint32_t)e);
+                        v[2 * e] = (hsh & 0xffffu) >= a.drop_thresh ? from_f32<T>(to_f32(v[2 * e]) * a.drop_scale) : from_f32<T>(0.f);
+                        v[2 * e + 1] = (hsh >> 16) >= a.drop_thresh ? from_f32<T>(to_f32(v[2 * e + 1]) * a.drop_scale) : from_f32<T>(0.f);
+                    }
                 }
             }
             if (Mk) {      // keep where the saved activation is > 0: for bf16 and fp32 alike that is "bit pattern > 0 as a signed integer"

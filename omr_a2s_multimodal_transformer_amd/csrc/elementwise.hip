@@ -332,7 +332,7 @@ extern "C" int omr_dropout(int dtype, const void* x, void* out, long n, float p,
                            long per_sample, int C, void* stream) {
     if (n <= 0) return OMR_OK;
     if (p < 0.f || p >= 1.f) return OMR_ERR_ARG;
-    uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    uint32_t thresh = OMR_DROP_THRESH16(p);
     float scale = 1.f / (1.f - p);
     hipStream_t s = (hipStream_t)stream;
     if (channel_mode) {

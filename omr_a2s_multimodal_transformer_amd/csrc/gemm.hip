@@ -421,7 +421,7 @@ extern "C" int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, i
         if ((row_group_operand == 2 && !transB) || (row_group_operand == 1 && transB)) return OMR_ERR_ARG;
         g.grp = row_group; g.grp_stride = row_group_stride; g.grp_base = row_group_base; g.grp_operand = row_group_operand;
     }
-    g.drop_thresh = (unsigned)((double)drop_p * 4294967296.0); g.drop_scale = 1.f / (1.f - drop_p); g.drop_seed = drop_seed;
+    g.drop_thresh = OMR_DROP_THRESH16(drop_p); g.drop_scale = 1.f / (1.f - drop_p); g.drop_seed = drop_seed;
     if (colsum_a && !transA) return OMR_ERR_ARG;
     const int bk = dtype == OMR_BF16 ? 64 : 32;
     int len = cdiv(cdiv(K, split_k), bk) * bk;

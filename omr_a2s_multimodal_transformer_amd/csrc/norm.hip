@@ -374,7 +374,7 @@ extern "C" int omr_add_layernorm_fwd(int dtype, const void* x, const void* res, 
     if (M <= 0 || d <= 0 || d % 64 || drop_p < 0.f || drop_p >= 1.f) return OMR_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     int grid = cdiv(M, 4);
-    const uint32_t thresh = (uint32_t)((double)drop_p * 4294967296.0);
+    const uint32_t thresh = OMR_DROP_THRESH16(drop_p);
     const float scale = 1.f / (1.f - drop_p);
     DISPATCH_T(dtype, { LN_DISPATCH_PER(add_ln_fwd_kernel, grid, 256, 0, s, (const T*)x, (const T*)res, gamma, beta, (T*)out, mean, rstd, M, eps, thresh, scale,
                                         (uint64_t)drop_seed) });
@@ -389,7 +389,7 @@ extern "C" int omr_add_layernorm_bwd(int dtype, const void* dy, const void* x, c
     hipStream_t s = (hipStream_t)stream;
     int rpb = 64;                        // fewer, longer workgroups: each ends with 2 d atomics onto the same 16 cache lines
     int grid = cdiv(M, rpb);
-    const uint32_t thresh = (uint32_t)((double)drop_p * 4294967296.0);
+    const uint32_t thresh = OMR_DROP_THRESH16(drop_p);
     const float scale = 1.f / (1.f - drop_p);
     if (thresh && !dx) return OMR_ERR_ARG;
     DISPATCH_T(dtype, { LN_DISPATCH_PER(add_ln_bwd_kernel, grid, 256, 0, s, (const T*)dy, (const T*)x, (const T*)res, gamma, mean, rstd, (T*)ds, dgamma, dbeta, M, rpb,

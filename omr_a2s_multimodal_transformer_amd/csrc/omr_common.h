@@ -99,9 +99,17 @@ __device__ __forceinline__ uint32_t hash32(uint32_t seed_lo, uint32_t seed_hi, u
     h ^= h >> 16;
     return h;
 }
-// keep iff hash >= p * 2^32
-__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-    return hash32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)idx ^ (uint32_t)(idx >> 32) * 0x27D4EB2Fu) >= thresh;
+// Dropout keep decision of element `idx` under (seed, p): ONE 32-bit hash serves the element PAIR (idx & ~1, idx | 1) with 16
+// random bits each (low half: even element), keep iff bits >= p * 2^16 (thresh16 = OMR_DROP_THRESH16(p); p is realised to
+// 1.5e-5, 0.5 and 0.25 exactly).  Every dropout site of the library uses this convention (omr_dropout, the conv / GEMM /
+// add+LayerNorm epilogues), so a mask can be regenerated anywhere from (seed, index); vector code hashes once per pair.
+#define OMR_DROP_THRESH16(p) ((uint32_t)((double)(p) * 65536.0 + 0.5))
+__device__ __forceinline__ uint32_t drop_pair_bits(uint64_t seed, uint64_t pair) {
+    return hash32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)pair ^ (uint32_t)(pair >> 32) * 0x27D4EB2Fu);
+}
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh16) {
+    const uint32_t h = drop_pair_bits(seed, idx >> 1);
+    return ((idx & 1) ? (h >> 16) : (h & 0xffffu)) >= thresh16;
 }
 
 __host__ __device__ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -19,7 +19,7 @@ import torch
 from torch.autograd import Function
 
 from . import kernels as K
-from .runtime import WgradStream
+from .runtime import WgradStream, note_relu
 
 Tensor = torch.Tensor
 
@@ -63,6 +63,8 @@ class Conv3x3Fn(Function):
         ws, slots = K.conv_stat_ws(B, Ho, Wo, cout, x.device) if want_stats else (None, 0)
         y = K.conv3x3(x, wt(weight, dt), bias.omr_phys, stride=stride, relu=relu, in_stats=in_stats, drop=drop,
                       stat_mode=1 if want_stats else 0, stat_ws=ws, stat_slots=slots)
+        if relu:
+            note_relu(y)
         own_scale = 1.0 / (1.0 - drop[0]) if drop is not None else 1.0
         ctx.cfg = (stride, relu, mask_own, mask_input, in_scale, own_scale)
         ctx.weight, ctx.bias, ctx.stats = weight, bias, in_stats
@@ -152,6 +154,8 @@ class LinearFn(Function):
         ctx.cfg = (relu, mask_own, tuple(x.shape), rows, 1.0 / (1.0 - drop[0]) if drop is not None else 1.0)
         ctx.weight, ctx.bias = weight, bias
         ctx.save_for_backward(x2, y2 if (relu and mask_own) else None)
+        if relu:
+            note_relu(y2.view(*x.shape[:-1], N))
         return y2.view(*x.shape[:-1], N)
 
     @staticmethod

@@ -49,6 +49,33 @@ class trace_dropout:
         return False
 
 
+_relu_trace = None     # list of bool tensors (y > 0) while a ReLU trace is being recorded
+
+
+def note_relu(y: torch.Tensor) -> None:
+    """Called by every kernel wrapper whose epilogue applied a ReLU (functional.Conv3x3Fn / LinearFn) with its stored output."""
+    if _relu_trace is not None:
+        _relu_trace.append(y.detach() > 0)
+
+
+class trace_relu:
+    """Context manager that records, in call order, the ReLU mask (stored output > 0) of every ReLU'd kernel output of the
+    forward passes run inside it: NHWC [B,H,W,C] maps for the encoder, [B,T,ff] for the decoder's feed-forward.  A checker
+    injects them into oracle.ref_cpu.DropPlan(relu_fn=...) so that the CPU gradient is taken on the same piecewise-linear
+    region as the HIP run (tests/test_dropout_parity_gpu.py).  Where a dropout is fused behind the ReLU the mask also
+    excludes the dropped elements, whose gradient is zero either way."""
+
+    def __enter__(self):
+        global _relu_trace
+        self.prev, _relu_trace = _relu_trace, []
+        return _relu_trace
+
+    def __exit__(self, *exc):
+        global _relu_trace
+        _relu_trace = self.prev
+        return False
+
+
 class WgradStream:
     """Side HIP stream for the decoder's weight-gradient GEMMs.  dW = dY^T X of a linear has no consumer inside backward
     and, at d_model = 256, fills a quarter of the CUs for a few tens of microseconds: issued on a second stream it runs

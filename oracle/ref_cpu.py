@@ -56,11 +56,19 @@ class DropPlan:
     (keep / (1 - p), broadcastable to ``shape``) of the site-th dropout call of the forward, in the reference's call order.
     kind: "nhwc" = a [B,C,H,W] feature map (MixDropout, PositionalEncoding2D; channel=True is nn.Dropout2d: one decision
     per (b, c)), "rows" = a [B,T,d] token tensor, "attn" = attention probabilities [B,nhead,T,S].  Sites with p = 0 are
-    identities and do not count."""
+    identities and do not count.
 
-    def __init__(self, mask_fn):
+    ``relu_fn(site, shape)`` (optional) additionally fixes the ReLU masks: the site-th ReLU of the forward becomes
+    ``x * mask`` (0/1, same shape), i.e. the network is evaluated on the piecewise-linear region the mask names.  With the
+    masks of another correct fp32 run the forward values are unchanged up to the few pre-activations within rounding noise
+    of zero, but the GRADIENT no longer depends on which side of zero those fall -- the only way two correct fp32
+    implementations of this network can differ by more than rounding noise (tests/test_dropout_parity_gpu.py)."""
+
+    def __init__(self, mask_fn, relu_fn=None):
         self.mask_fn = mask_fn
+        self.relu_fn = relu_fn
         self.sites = 0
+        self.relu_sites = 0
 
     def apply(self, x: Tensor, kind: str, p: float, channel: bool = False) -> Tensor:
         if p <= 0.0:
@@ -69,9 +77,21 @@ class DropPlan:
         self.sites += 1
         return x * m
 
+    def relu(self, x: Tensor) -> Tensor:
+        if self.relu_fn is None:
+            return F.relu(x)
+        m = self.relu_fn(self.relu_sites, tuple(x.shape))
+        self.relu_sites += 1
+        return x * m
+
 
 def _drop(drop: Optional[DropPlan], x: Tensor, kind: str, p: float) -> Tensor:
     return x if drop is None else drop.apply(x, kind, p)
+
+
+def _relu(drop: Optional[DropPlan], x: Tensor) -> Tensor:
+    """nn.ReLU (encoder.py:127,202; TransformerDecoderLayer activation): plain, or with an injected mask (DropPlan.relu)."""
+    return F.relu(x) if drop is None else drop.relu(x)
 
 
 def mix_dropout(drop: Optional[DropPlan], x: Tensor, p: float) -> Tensor:
@@ -103,14 +123,14 @@ def conv_block(sd: SD, p: str, x: Tensor, stride: Tuple[int, int], drop: Optiona
     """ConvBlock.forward, encoder.py:159-181.  With a DropPlan: pos = random.randint(1, 3) picks the conv after whose
     ReLU the MixDropout is applied (encoder.py:160-179)."""
     pos = random.randint(1, 3) if drop is not None else 0
-    x = F.relu(F.conv2d(x, sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1))
+    x = _relu(drop, F.conv2d(x, sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1))
     if pos == 1:
         x = mix_dropout(drop, x, dp)
-    x = F.relu(F.conv2d(x, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1))
+    x = _relu(drop, F.conv2d(x, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1))
     if pos == 2:
         x = mix_dropout(drop, x, dp)
     x = instance_norm(x)
-    x = F.relu(F.conv2d(x, sd[p + "conv3.weight"], sd[p + "conv3.bias"], padding=1, stride=stride))
+    x = _relu(drop, F.conv2d(x, sd[p + "conv3.weight"], sd[p + "conv3.bias"], padding=1, stride=stride))
     if pos == 3:
         x = mix_dropout(drop, x, dp)
     return x
@@ -126,10 +146,10 @@ def depth_sep_conv(sd: SD, p: str, x: Tensor) -> Tensor:
 def dsc_block(sd: SD, p: str, x: Tensor, drop: Optional[DropPlan] = None, dp: float = 0.5) -> Tensor:
     """DSCBlock.forward, encoder.py:218-238 (no ReLU after conv3; all strides (1,1) :264-267)."""
     pos = random.randint(1, 3) if drop is not None else 0
-    x = F.relu(depth_sep_conv(sd, p + "conv1.", x))
+    x = _relu(drop, depth_sep_conv(sd, p + "conv1.", x))
     if pos == 1:
         x = mix_dropout(drop, x, dp)
-    x = F.relu(depth_sep_conv(sd, p + "conv2.", x))
+    x = _relu(drop, depth_sep_conv(sd, p + "conv2.", x))
     if pos == 2:
         x = mix_dropout(drop, x, dp)
     x = instance_norm(x)
@@ -278,7 +298,7 @@ def decoder_layer(sd: SD, p: str, x: Tensor, memory: Tensor, self_bias: Tensor, 
     ca = mha(x, memory, sd[p + "multihead_attn.in_proj_weight"], sd[p + "multihead_attn.in_proj_bias"],
              sd[p + "multihead_attn.out_proj.weight"], sd[p + "multihead_attn.out_proj.bias"], nhead, mem_bias, drop, dp)
     x = layer_norm(x + _drop(drop, ca, "rows", dp), sd[p + "norm2.weight"], sd[p + "norm2.bias"])
-    h = _drop(drop, F.relu(F.linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"])), "rows", dp)
+    h = _drop(drop, _relu(drop, F.linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"])), "rows", dp)
     ff = F.linear(h, sd[p + "linear2.weight"], sd[p + "linear2.bias"])
     return layer_norm(x + _drop(drop, ff, "rows", dp), sd[p + "norm3.weight"], sd[p + "norm3.bias"])
 
