@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? (CK == 16 ? 4 : 3) : 2)
         const T* Mk = a.mask ? (const T*)a.mask + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
         const T* SX = stat2 ? (const T*)a.stat_x + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
         const uint64_t img_base = (uint64_t)b * a.Ho * a.Wo * a.COUT;
-#pragma unroll(EPI == 0 ? 8 : 1)
+#pragma unroll(EPI == 0 ? 8 : 4)
         for (int c = tid; c < TH * TW * CPO; c += 256) {
             const int pl = c / CPO, kc = (c % CPO) * VEC;
             const int oh = oh0 + pl / TW, ow = ow0 + pl % TW, n = n0 + kc;
