@@ -170,6 +170,21 @@ int omr_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, flo
 int omr_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                  long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
                  const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed, void* stream);
+/* omr_attn_fwd / omr_attn_bwd with caller-provided scratch that lets the library split the KEYS of a (batch, head, query block)
+ * over several workgroups where that fills the chip better (the query-per-lane kernels have B*H*T/32 waves whatever S is:
+ * 2 per SIMD at B 32, T 512): partial softmaxes / partial dQ sums are merged by fixed-order kernels, results are
+ * deterministic.  ws: omr_attn_workspace_floats(B, H, T, S, head_dim, causal, backward) floats (0 = this shape is not split;
+ * NULL / 0 is then fine).  Same arguments and semantics as omr_attn_fwd / omr_attn_bwd otherwise. */
+long omr_attn_workspace_floats(int B, int H, int T, int S, int head_dim, int causal, int backward);
+int omr_attn_fwd_ws(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
+                    long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
+                    const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed, float* ws,
+                    long ws_floats, void* stream);
+int omr_attn_bwd_ws(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta_ws,
+                    void* dq, void* dk, void* dv, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, long bsq,
+                    long bsk, long bsv, long bso, long bsdo, long bsdq, long bsdk, long bsdv, int B, int H, int T, int S, int head_dim,
+                    int causal, int window, const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p,
+                    unsigned long long seed, float* ws, long ws_floats, void* stream);
 /* omr_attn_fwd for ONE block of at most 32 query rows (KV-cached decode: T = 1) with the keys split over workgroups of 256 keys
  * (partial softmaxes merged by a second small kernel): a single query row would otherwise keep each (batch, head) on one
  * workgroup walking all S keys.  No causal / block masks (a decode step sees every cached key), no dropout.

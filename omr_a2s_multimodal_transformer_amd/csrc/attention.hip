@@ -162,7 +162,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float bias_s[BST];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = SPLITW ? 0 : blockIdx.x * 128;      // SPLITW: blockIdx.x = key split
+    // blockIdx.x = key split (SPLITW: one query block) or query block + nqb * key split
+    const int nqb = SPLITW ? 1 : (a.T + 127) / 128;
+    const int ksplit = blockIdx.x / nqb, q0 = (blockIdx.x % nqb) * 128;
+    const int b = blockIdx.z, h = blockIdx.y;
     const int q = q0 + (SPLITW ? 0 : wave * 32) + (lane & 31);
     const int kboff = SPLITW ? wave * BKV : 0;                  // this wave's keys inside the staged block
     const T* Q = (const T*)a.q + (long)b * a.bsq + h * HD;
@@ -191,9 +194,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         kv_end = min(a.S, q0 + 128);
         if (a.window > 0 && a.window < a.T) kv_beg = max(0, q0 - a.window) / BKV * BKV;
     }
-    if constexpr (SPLITW) {
-        if (a.nsplit > 1) { kv_beg = blockIdx.x * a.split_len; kv_end = min(a.S, kv_beg + a.split_len); }
-    }
+    if (a.nsplit > 1) { kv_beg = max(kv_beg, ksplit * a.split_len); kv_end = min(kv_end, (ksplit + 1) * a.split_len); }
     RowTile<T, HD, BST> kt, vt;
     float bias_r = 0.f;
     auto prefetch = [&](int kvb) {
@@ -340,18 +341,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 acc_o[d][r] = v;
             }
     }
-    if constexpr (SPLITW) {
-        if (a.nsplit > 1) {          // partial softmax of this key split: un-normalised O, running max (log2 domain) and sum
-            if (q < a.T) {
-                float* P = a.part + ((((long)b * a.H + h) * a.nsplit + blockIdx.x) * a.T + q) * (HD + 2);
+    if (a.nsplit > 1) {          // partial softmax of this key split: un-normalised O, running max (log2 domain) and sum
+        if (q < a.T) {
+            float* P = a.part + ((((long)b * a.H + h) * a.nsplit + ksplit) * a.T + q) * (HD + 2);
 #pragma unroll
-                for (int d = 0; d < NDB; ++d)
+            for (int d = 0; d < NDB; ++d)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) P[d * 32 + acc_row(r, lane)] = acc_o[d][r];
-                if (hh == 0) { P[HD] = m_run; P[HD + 1] = l_tot; }
-            }
-            return;
+                for (int r = 0; r < 16; ++r) P[d * 32 + acc_row(r, lane)] = acc_o[d][r];
+            if (hh == 0) { P[HD] = m_run; P[HD + 1] = l_tot; }
         }
+        return;
     }
     const float inv = l_tot > 0.f ? a.drop_scale / l_tot : 0.f;      // dropout rescale folded in (1 when p = 0)
     if (q < a.T) {
@@ -417,7 +416,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float bias_s[BKV];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int nqb = (a.T + 127) / 128;                          // blockIdx.x = query block + nqb * key split
+    const int ksplit = blockIdx.x / nqb, q0 = (blockIdx.x % nqb) * 128;
+    const int b = blockIdx.z, h = blockIdx.y;
     const int q = q0 + wave * 32 + (lane & 31);
     const T* Q = (const T*)a.q + (long)b * a.bsq + h * HD;
     const T* K = (const T*)a.k + (long)b * a.bsk + h * HD;
@@ -451,6 +452,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         kv_end = min(a.S, q0 + 128);
         if (a.window > 0 && a.window < a.T) kv_beg = max(0, q0 - a.window) / BKV * BKV;
     }
+    if (a.nsplit > 1) { kv_beg = max(kv_beg, ksplit * a.split_len); kv_end = min(kv_end, (ksplit + 1) * a.split_len); }
     RowTile<T, HD, BKV> kt, vt;
     float bias_r = 0.f;
     auto prefetch = [&](int kv0) {
@@ -516,11 +518,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         }
     }
     if (q < a.T) {
-        T* DQ = (T*)a.dq + (long)b * a.bsdq + (long)q * a.lddq + h * HD;
+        if (a.nsplit > 1) {          // partial dQ of this key split, fp32 [nsplit][B][T][H*HD]: summed by attn_dq_sum_kernel
+            float* PQ = a.part + ((((long)ksplit * a.B + b) * a.T + q) * a.H + h) * HD;
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
+            for (int d = 0; d < NDB; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) DQ[d * 32 + acc_row(r, lane)] = from_f32<T>(acc_q[d][r] * a.scale);
+                for (int r = 0; r < 16; ++r) PQ[d * 32 + acc_row(r, lane)] = acc_q[d][r] * a.scale;
+        } else {
+            T* DQ = (T*)a.dq + (long)b * a.bsdq + (long)q * a.lddq + h * HD;
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) DQ[d * 32 + acc_row(r, lane)] = from_f32<T>(acc_q[d][r] * a.scale);
+        }
+    }
+}
+
+// dq[b][q][c] = sum over key splits of the fp32 partials (fixed order), c over the H*HD channels
+template <typename T>
+__global__ void attn_dq_sum_kernel(AttnArgs a, int hd) {
+    const long per = (long)a.B * a.T * a.H * hd, cols = (long)a.H * hd;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int j = 0; j < a.nsplit; ++j) s += a.part[j * per + i];
+        const long c = i % cols, bq = i / cols, qq = bq % a.T, bb = bq / a.T;
+        ((T*)a.dq)[bb * a.bsdq + qq * a.lddq + c] = from_f32<T>(s);
     }
 }
 
@@ -706,15 +728,20 @@ template <typename T, int HD> int run_fwd(const AttnArgs& a, hipStream_t s) {
         OMR_CHECK_LAUNCH();
         return OMR_OK;
     }
-    dim3 grid(cdiv(a.T, 128), a.H, a.B);
+    dim3 grid(cdiv(a.T, 128) * (a.nsplit > 1 ? a.nsplit : 1), a.H, a.B);
     hipLaunchKernelGGL((attn_fwd_kernel<T, HD, false>), grid, dim3(256), 0, s, a);
+    if (a.nsplit > 1) hipLaunchKernelGGL((attn_split_merge_kernel<T, HD>), dim3(a.B * a.H * a.T), dim3(64), 0, s, a);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }
 template <typename T, int HD> int run_bwd(const AttnArgs& a, hipStream_t s) {
     long n = (long)a.B * a.H * a.T;
     hipLaunchKernelGGL((attn_delta_kernel<T, HD>), cdiv(n, 256), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), dim3(cdiv(a.T, 128), a.H, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), dim3(cdiv(a.T, 128) * (a.nsplit > 1 ? a.nsplit : 1), a.H, a.B), dim3(256), 0, s, a);
+    if (a.nsplit > 1) {
+        long nsum = (long)a.B * a.T * a.H * HD, gs = (nsum + 255) / 256;
+        hipLaunchKernelGGL((attn_dq_sum_kernel<T>), dim3((unsigned)(gs > 4096 ? 4096 : gs)), dim3(256), 0, s, a, HD);
+    }
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD>), dim3(cdiv(a.S, 128), a.H, a.B), dim3(256), 0, s, a);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
@@ -748,10 +775,53 @@ extern "C" int omr_attn_dropout_mask(unsigned char* mask, int B, int H, int T, i
     return OMR_OK;
 }
 
+// Key split of the lane-per-query kernels (forward, dQ).  They own 32 query rows per wave, so B*H*T/32 waves exist whatever
+// the key count: 2 per SIMD at the benchmark's cross-attention (B 32, H 4, T 512, S 4096) -- too few to hide the LDS / barrier /
+// load latencies of a 64-key tile (measured: 4 000 SIMD cycles per wave-tile against ~1 900 of issue).  Splitting the KEYS of
+// a (batch, head, query block) over several workgroups multiplies the resident waves; the forward's partial softmaxes are
+// merged by attn_split_merge_kernel, the partial dQ sums by attn_dq_sum_kernel (both fixed-order, no atomics).  Decode
+// (T <= 32): one 256-key block per workgroup.  Causal attention is not split (its key range depends on the query block).
+static void choose_split(int B, int H, int T, int S, int causal, int* nsplit, int* split_len) {
+    *nsplit = 1; *split_len = 0;
+    if (causal || S <= 256) return;
+    int want;
+    if (T <= 32) want = (S + 255) / 256;
+    else {
+        const long blocks = (long)B * H * ((T + 127) / 128);
+        want = (int)((512 + blocks - 1) / blocks);               // at least ~512 workgroups (2 per CU); more buys nothing: the
+                                                                  // kernels are VALU-issue bound, not latency bound (measured)
+        const int maxs = S / 512;                                 // at least 512 keys per split
+        if (want > maxs) want = maxs;
+    }
+    if (want <= 1) return;
+    const int len = ((S + want - 1) / want + 255) / 256 * 256;    // whole 256-key staging blocks
+    *split_len = len; *nsplit = (S + len - 1) / len;
+    if (*nsplit <= 1) { *nsplit = 1; *split_len = 0; }
+}
+
+/* floats of scratch omr_attn_fwd_ws / omr_attn_bwd_ws want for a shape (0: the shape is not split) */
+extern "C" long omr_attn_workspace_floats(int B, int H, int T, int S, int head_dim, int causal, int backward) {
+    if (B <= 0 || H <= 0 || T <= 0 || S <= 0) return 0;
+    int nsplit, len;
+    choose_split(B, H, T, S, causal, &nsplit, &len);
+    if (nsplit <= 1) return 0;
+    return backward ? (long)nsplit * B * T * H * head_dim : (long)B * H * nsplit * T * (head_dim + 2);
+}
+
 static int attn_fwd_impl(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                          long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
                          const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed,
                          float* split_ws, long split_ws_floats, void* stream);
+
+/* omr_attn_fwd with caller-provided scratch for the key split (omr_attn_workspace_floats(..., backward = 0) floats) */
+extern "C" int omr_attn_fwd_ws(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
+                               long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
+                               const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed,
+                               float* ws, long ws_floats, void* stream) {
+    return attn_fwd_impl(dtype, q, k, v, o, lse, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, T, S, head_dim, causal, window, key_bias, blk_lq, blk_lkv,
+                         dropout_p, seed, ws, ws_floats, stream);
+}
+
 
 extern "C" int omr_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                             long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
@@ -763,9 +833,8 @@ extern "C" int omr_attn_fwd(int dtype, const void* q, const void* k, const void*
 
 /* floats of split workspace omr_attn_fwd_split wants for (B, H, T <= 32, S): partial softmaxes of the key splits */
 extern "C" long omr_attn_split_workspace_floats(int B, int H, int T, int S, int head_dim) {
-    if (B <= 0 || H <= 0 || T <= 0 || T > 32 || S <= 0) return 0;
-    const int nsplit = (S + 255) / 256;
-    return nsplit > 1 ? (long)B * H * nsplit * T * (head_dim + 2) : 0;
+    if (T > 32) return 0;
+    return omr_attn_workspace_floats(B, H, T, S, head_dim, 0, 0);
 }
 
 /* omr_attn_fwd for a single block of at most 32 query rows (KV-cached decode) with the KEYS split over workgroups of 256 keys
@@ -790,10 +859,13 @@ static int attn_fwd_impl(int dtype, const void* q, const void* k, const void* v,
     a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.bsq = bsq; a.bsk = bsk; a.bsv = bsv; a.bso = bso;
     a.nsplit = 1; a.split_len = 0; a.part = nullptr;
-    if (split_ws && T <= 32 && S > 256) {
-        const int nsplit = (S + 255) / 256;
-        if (split_ws_floats < (long)B * H * nsplit * T * (head_dim + 2)) return OMR_ERR_ARG;
-        a.nsplit = nsplit; a.split_len = 256; a.part = split_ws;
+    if (split_ws) {
+        int nsplit, len;
+        choose_split(B, H, T, S, causal, &nsplit, &len);
+        if (nsplit > 1) {
+            if (split_ws_floats < (long)B * H * nsplit * T * (head_dim + 2)) return OMR_ERR_ARG;
+            a.nsplit = nsplit; a.split_len = len; a.part = split_ws;
+        }
     }
     hipStream_t s = (hipStream_t)stream;
     if (dtype == OMR_BF16) return head_dim == 64 ? run_fwd<bf16, 64>(a, s) : run_fwd<bf16, 32>(a, s);
@@ -806,6 +878,16 @@ extern "C" int omr_attn_bwd(int dtype, const void* q, const void* k, const void*
                             long lddk, long lddv, long bsq, long bsk, long bsv, long bso, long bsdo, long bsdq, long bsdk, long bsdv, int B,
                             int H, int T, int S, int head_dim, int causal, int window, const float* key_bias, const int* blk_lq,
                             const int* blk_lkv, float dropout_p, unsigned long long seed, void* stream) {
+    return omr_attn_bwd_ws(dtype, q, k, v, o, dout, lse, delta_ws, dq, dk, dv, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, bsq, bsk, bsv, bso, bsdo, bsdq,
+                           bsdk, bsdv, B, H, T, S, head_dim, causal, window, key_bias, blk_lq, blk_lkv, dropout_p, seed, nullptr, 0, stream);
+}
+
+/* omr_attn_bwd with caller-provided scratch for the key split of the dQ kernel (omr_attn_workspace_floats(..., backward = 1)) */
+extern "C" int omr_attn_bwd_ws(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                               float* delta_ws, void* dq, void* dk, void* dv, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq,
+                               long lddk, long lddv, long bsq, long bsk, long bsv, long bso, long bsdo, long bsdq, long bsdk, long bsdv, int B,
+                               int H, int T, int S, int head_dim, int causal, int window, const float* key_bias, const int* blk_lq,
+                               const int* blk_lkv, float dropout_p, unsigned long long seed, float* ws, long ws_floats, void* stream) {
     AttnArgs a = {};
     int rc = fill_common(a, B, H, T, S, head_dim, dropout_p, seed, causal, window, key_bias, blk_lq, blk_lkv);
     if (rc) return rc;
@@ -815,6 +897,15 @@ extern "C" int omr_attn_bwd(int dtype, const void* q, const void* k, const void*
     a.q = q; a.k = k; a.v = v; a.o = (void*)o; a.lse = (float*)lse; a.dout = dout; a.delta = delta_ws; a.dq = dq; a.dk = dk; a.dv = dv;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     a.bsq = bsq; a.bsk = bsk; a.bsv = bsv; a.bso = bso; a.bsdo = bsdo; a.bsdq = bsdq; a.bsdk = bsdk; a.bsdv = bsdv;
+    a.nsplit = 1; a.split_len = 0; a.part = nullptr;
+    if (ws && T > 32) {
+        int nsplit, len;
+        choose_split(B, H, T, S, causal, &nsplit, &len);
+        if (nsplit > 1) {
+            if (ws_floats < (long)nsplit * B * T * H * head_dim) return OMR_ERR_ARG;
+            a.nsplit = nsplit; a.split_len = len; a.part = ws;
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     if (dtype == OMR_BF16) return head_dim == 64 ? run_bwd<bf16, 64>(a, s) : run_bwd<bf16, 32>(a, s);
     if (dtype == OMR_F32) return head_dim == 64 ? run_bwd<float, 64>(a, s) : run_bwd<float, 32>(a, s);

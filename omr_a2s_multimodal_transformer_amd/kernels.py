@@ -418,9 +418,16 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, nhead: int, *, causal: bool = Fals
         if t is not None:
             assert t.dtype == torch.int32 and t.numel() == B and t.is_contiguous()
     (ldq, bsq), (ldk, bsk), (ldv, bsv), (ldo, bso) = _bts(q), _bts(k), _bts(v), _bts(o)
-    lib().call("omr_attn_fwd", dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, nhead, T, S, hd,
-               int(causal), int(window), ptr(key_bias), ptr(blk_lq), ptr(blk_lkv), float(dropout_p), int(seed) & (2**64 - 1), cur_stream())
+    ws, nws = _attn_ws(B, nhead, T, S, hd, causal, False, q.device)
+    lib().call("omr_attn_fwd_ws", dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, nhead, T, S, hd,
+               int(causal), int(window), ptr(key_bias), ptr(blk_lq), ptr(blk_lkv), float(dropout_p), int(seed) & (2**64 - 1), ptr(ws), nws, cur_stream())
     return o, lse
+
+
+def _attn_ws(B: int, H: int, T: int, S: int, hd: int, causal: bool, backward: bool, device):
+    """Scratch for the key split of the query-per-lane attention kernels (include/omr_hip.h omr_attn_workspace_floats)."""
+    n = lib().query("omr_attn_workspace_floats", B, H, T, S, hd, int(causal), int(backward))
+    return (torch.empty(n, dtype=torch.float32, device=device), n) if n > 0 else (None, 0)
 
 
 def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, nhead: int, *, causal=False, window=-1, key_bias=None, blk_lq=None, blk_lkv=None,
@@ -434,9 +441,10 @@ def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, nhead: int, *, causal=False, win
     assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape and dout.shape == o.shape
     (ldq, bsq), (ldk, bsk), (ldv, bsv), (ldo, bso), (lddo, bsdo) = _bts(q), _bts(k), _bts(v), _bts(o), _bts(dout)
     (lddq, bsdq), (lddk, bsdk), (lddv, bsdv) = _bts(dq), _bts(dk), _bts(dv)
-    lib().call("omr_attn_bwd", dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ldq, ldk,
+    ws, nws = _attn_ws(B, nhead, T, S, hd, causal, True, q.device)
+    lib().call("omr_attn_bwd_ws", dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ldq, ldk,
                ldv, ldo, lddo, lddq, lddk, lddv, bsq, bsk, bsv, bso, bsdo, bsdq, bsdk, bsdv, B, nhead, T, S, hd, int(causal), int(window),
-               ptr(key_bias), ptr(blk_lq), ptr(blk_lkv), float(dropout_p), int(seed) & (2**64 - 1), cur_stream())
+               ptr(key_bias), ptr(blk_lq), ptr(blk_lkv), float(dropout_p), int(seed) & (2**64 - 1), ptr(ws), nws, cur_stream())
 
 
 def attn_dropout_mask(B: int, H: int, T: int, S: int, p: float, seed: int, device) -> Tensor:
