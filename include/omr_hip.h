@@ -125,6 +125,15 @@ int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, int N, int K
              long ldc, const float* bias, int relu, int accumulate, int split_k, float* colsum_a, float drop_p,
              unsigned long long drop_seed, int row_group, int row_group_stride, int row_group_base, int row_group_operand, void* stream);
 
+/* fp8 path (BASELINE config 5 "fp8 MFMA weights"; an extension -- the reference has no fp8; inference only).  Operands are
+ * OCP e4m3 with one fp32 scale per ROW: weights [N][K] quantised once (scale per output feature), activations [M][K] per
+ * token on the fly.  omr_quantize_rows_fp8: scale[m] = absmax(row) / 448, q = round_to_fp8(x / scale) (x in `dtype`).
+ * omr_gemm_fp8: C[M][N] = (A8 . W8^T) * scale_a[m] * scale_w[n] + bias[n] [-> ReLU], products on the fp8 MFMA
+ * (v_mfma_f32_32x32x16_fp8_fp8), fp32 accumulation, C in c_dtype; K and both row strides multiples of 16. */
+int omr_quantize_rows_fp8(int dtype, const void* x, long ldx, unsigned char* q, long ldq, float* scale, int M, int K, void* stream);
+int omr_gemm_fp8(int c_dtype, int M, int N, int K, const unsigned char* A8, long lda, const float* scale_a, const unsigned char* W8, long ldb,
+                 const float* scale_w, void* C, long ldc, const float* bias, int relu, void* stream);
+
 /* Weight (and bias) gradients of SEVERAL linear layers in one launch: for each problem dw[n_out][n_in] += dy^T . x and
  * db[n_out] += column sums of dy (db nullable), reducing over `rows`; dy [rows][ld_dy], x [rows][ld_x] in `dtype`, dw / db fp32
  * accumulators (fp32 atomics: the buffers hold the running sums).  A linear's dW at d_model = 256 is too small to fill the
@@ -144,9 +153,12 @@ int omr_linear_wgrad_grouped(int dtype, int nprob, const omr_dw_problem* problem
  * gradient of a strided conv.  CIN == 1 takes the direct (non-MFMA) first-layer path. */
 /* Fused on the output: MixDropout after the ReLU (drop_p > 0; encoder.py:165-179; elementwise mask keyed by the flat NHWC
  * index, or per (image, channel) when drop_channel_mode) and a per-(image, channel) reduction over the stored tile into
- * fp64 stat_ws[B][COUT][2] (zeroed by the caller): stat_mode 1 = {sum y, sum y^2} (InstanceNorm statistics of this
- * output, finalised by omr_instnorm_finalize), stat_mode 2 = {sum g, sum g*xhat} with xhat = (stat_x - mean)*rstd
- * (InstanceNorm backward sums when this call is the data gradient that produces g = dL/dxhat). */
+ * the fp64 slots stat_ws[B][stat_slots][COUT][2] (every slot is written; stat_slots = omr_conv3x3_stat_slots(B, Ho, Wo), an
+ * upper bound on the persistent grid's blocks per image; deterministic, see "normalisation"): stat_mode 1 = {sum y, sum y^2}
+ * (InstanceNorm statistics of this output, finalised by omr_instnorm_finalize), stat_mode 2 = {sum g, sum g*xhat} with
+ * xhat = (stat_x - mean)*rstd (InstanceNorm backward sums when this call is the data gradient that produces g = dL/dxhat;
+ * consumed by omr_instnorm_bwd_apply). */
+int omr_conv3x3_stat_slots(int B, int Ho, int Wo);
 int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const float* bias, void* y, const float* in_mean, const float* in_rstd,
                     const void* out_mask, float mask_scale, int B, int H, int W, int CIN, int COUT, int stride_h, int stride_w, int dil_h,
                     int dil_w, int Ho, int Wo, int relu, float drop_p, unsigned long long drop_seed, int drop_channel_mode,
@@ -219,10 +231,17 @@ int omr_attn_bwd(int dtype, const void* q, const void* k, const void* v, const v
  * (matrices in `dtype`, biases / LayerNorm vectors fp32).  self_kv [L][B][max_len][2d]; cross_kv: layer l's K|V rows of
  * sample b, key s at cross_kv + b*cross_bs + s*cross_ld + l*2d (elements; cross_bs = 0 shares one memory between rows). */
 #define OMR_DECODE_LAYER_PTRS 18
+/* fp8 != 0 (BASELINE config 5 "fp8 MFMA weights", an extension): the linears run as omr_quantize_rows_fp8 + omr_gemm_fp8 on
+ * weights quantised once per output row.  layer_w8 / layer_s8: HOST arrays [L][OMR_DECODE_LAYER_FP8] of device pointers to the
+ * e4m3 codes [rows][in] and fp32 row scales of, in order: self_attn.in_proj_weight, self_attn.out_proj.weight,
+ * multihead_attn.in_proj_weight, multihead_attn.out_proj.weight, linear1.weight, linear2.weight; head_w8 / head_s8: the head.
+ * Biases, LayerNorm, embedding, attention and the cross-attention K|V (projected once at init) stay in `dtype`. */
+#define OMR_DECODE_LAYER_FP8 6
 typedef struct omr_decode_desc {
-    int dtype, B, L, d, nhead, ff, V, ldv, max_len, S, window, reserved;
+    int dtype, B, L, d, nhead, ff, V, ldv, max_len, S, window, fp8;
     const void* emb; const float* pe; const void* const* layer_w; const void* head_w; const float* head_b;
     void* self_kv; const void* cross_kv; long cross_ld, cross_bs; void* ws; long ws_bytes;
+    const unsigned char* const* layer_w8; const float* const* layer_s8; const unsigned char* head_w8; const float* head_s8;
 } omr_decode_desc;
 long omr_decode_workspace_bytes(const omr_decode_desc* desc);
 int omr_decode_steps(const omr_decode_desc* desc, long* tokens, int t0, int n_steps, long* out_tokens, float* out_top1, float* last_logits,

@@ -62,18 +62,20 @@ class _Lib:
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
+        self.fns = {}                      # name -> bound foreign function (one dict lookup per launch on the hot path)
         for name, (ret, types) in self.protos.items():
             fn = getattr(self.cdll, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = ctypes.c_long if ret == "long" else ctypes.c_int
             fn.argtypes = [_ctype(t) for t in types]
+            self.fns[name] = fn
 
     def call(self, name: str, *args):
-        rc = getattr(self.cdll, name)(*args)
+        rc = self.fns[name](*args)
         if rc != 0:
             raise RuntimeError(f"libomr_hip: {name} failed: {_ERRORS.get(rc, rc)}")
 
     def query(self, name: str, *args) -> int:
-        return int(getattr(self.cdll, name)(*args))
+        return int(self.fns[name](*args))
 
 
 _LIB = None
@@ -90,11 +92,17 @@ def ptr(t):
     """Device pointer of a tensor (None -> NULL).  Tensors must be contiguous in the layout the kernel expects."""
     if t is None:
         return None
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()          # a plain int: ctypes converts it for a void* parameter without an intermediate object
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def cur_stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t of torch's current stream on the current device, as an int (0 = the default stream -> NULL)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device()) or None
+    return torch.cuda.current_stream().cuda_stream or None
 
 
 def require_cuda(*tensors) -> None:

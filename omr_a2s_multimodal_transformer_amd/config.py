@@ -21,6 +21,7 @@ class ModelConfig:
     dropout: float = 0.1        # decoder.py:65, model.py:29 (PE dropouts)
     encoder_dropout: float = 0.5  # encoder.py:251
     compute_dtype: str = "fp32"   # "fp32" (parity mode) or "bf16" (fp32 master weights + Adam)
+    fp8_decode: bool = False      # BASELINE config 5 (extension): greedy / beam decode with fp8 (e4m3) MFMA weights in the decoder
 
     def to_dict(self) -> Dict[str, Any]:
         return asdict(self)

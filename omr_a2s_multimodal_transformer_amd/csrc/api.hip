@@ -1,3 +1,3 @@
 // ABI version stamp of libomr_hip.so (bumped whenever include/omr_hip.h changes incompatibly).
 #include "omr_hip.h"
-extern "C" int omr_abi_version(void) { return 1; }
+extern "C" int omr_abi_version(void) { return 2; }

@@ -44,6 +44,29 @@ __device__ __forceinline__ TileId tile_of_block(const GemmArgs& g, int L) {     
 
 constexpr int BM = 128, BN = 128;
 
+}  // namespace
+
+// ---- fp8 (OCP e4m3) operands: 16 values per 16-byte fragment, two v_mfma_f32_32x32x16_fp8_fp8 per fragment pair -------------
+typedef unsigned char fp8;
+typedef __attribute__((ext_vector_type(16))) unsigned char u8x16;
+template <> struct Frag<fp8> {
+    typedef u8x16 type;
+    static constexpr int N = 16;
+};
+template <> __device__ __forceinline__ fp8 from_f32<fp8>(float x) { return (fp8)(__builtin_amdgcn_cvt_pk_fp8_f32(x, 0.f, 0, false) & 0xff); }
+__device__ __forceinline__ float to_f32(fp8 x) { return __builtin_amdgcn_cvt_f32_fp8((int)x, 0); }
+__device__ __forceinline__ void mma32(f32x16& acc, u8x16 a, u8x16 b) {
+    // lane half h holds k = 16h .. 16h+15 of the 32-wide k-step; instruction i takes bytes [8i, 8i+8) of both operands: A and B
+    // use the same (arbitrary) k order, so the sum is the dot product over all 32 k
+    long a2[2], b2[2];
+    __builtin_memcpy(a2, &a, 16);
+    __builtin_memcpy(b2, &b, 16);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a2[0], b2[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a2[1], b2[1], acc, 0, 0, 0);
+}
+
+namespace {
+
 // physical - logical row offset of the tile that starts at logical row i (tiles never straddle a group: host-checked)
 __device__ __forceinline__ long grp_delta(const GemmArgs& g, int operand, int i) {
     return g.grp_operand == operand ? (long)(i / g.grp) * (g.grp_stride - g.grp) + g.grp_base : 0;
@@ -151,7 +174,7 @@ template <typename T, typename TC, bool TA, bool TB, bool FULLK>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int block_index) {
     typedef GemmCfg<T> Cfg;
     typedef typename Frag<T>::type F;
-    constexpr bool SWAP = std::is_same<TC, bf16>::value;     // bf16 output: transposed accumulators + LDS-staged stores
+    constexpr bool SWAP = std::is_same<TC, bf16>::value && std::is_same<T, bf16>::value;     // bf16 in/out: transposed accumulators + LDS-staged stores
     __shared__ __attribute__((aligned(16))) T smem[Cfg::LDS_ELEMS];
     T* As = smem;
     T* Bs = smem + Cfg::OP_ELEMS;
@@ -330,7 +353,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int block_ind
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
                     if (row >= g.M) continue;
-                    float v = acc[i][j][r] + bv;
+                    float v = acc[i][j][r];
+                    if constexpr (std::is_same<T, fp8>::value) v *= g.scale_a[row] * g.scale_b[col];      // de-quantise: per-row scales of both operands
+                    v += bv;
                     if (g.relu) v = fmaxf(v, 0.f);
                     if constexpr (!TA) {      // forward-type GEMMs only: the weight-gradient instantiations keep their lean atomic loop
                         if (g.drop_thresh) v = drop_keep(g.drop_seed, (uint64_t)((long)row * g.ldc + col), g.drop_thresh) ? to_f32(from_f32<TC>(v)) * g.drop_scale : 0.f;
@@ -379,6 +404,7 @@ __global__ __launch_bounds__(256) void gemm_dw_grouped_kernel(DwGroup grp) {
     g.mt = q.mt; g.nt = q.nt; g.chunk = q.chunk; g.total = q.total;
     g.drop_thresh = 0; g.drop_scale = 1.f; g.drop_seed = 0;
     g.grp = q.grp; g.grp_stride = q.grp_stride; g.grp_base = q.grp_base; g.grp_operand = q.grp ? 3 : 0;
+    g.scale_a = nullptr; g.scale_b = nullptr;
     gemm_body<T, float, true, true, false>(g, (int)blockIdx.x - q.block0);
 }
 
@@ -416,6 +442,7 @@ extern "C" int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, i
     g.relu = relu; g.accum = accumulate; g.atomic = split_k > 1; g.colsum_a = colsum_a;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (split_k > 1 || accumulate || transA))) return OMR_ERR_ARG;      // dropout needs the final value
     g.grp = g.grp_stride = g.grp_base = g.grp_operand = 0;
+    g.scale_a = g.scale_b = nullptr;
     if (row_group_operand) {
         if (row_group_operand < 1 || row_group_operand > 3 || row_group <= 0 || row_group % 128 || row_group_stride < row_group || row_group_base < 0) return OMR_ERR_ARG;
         if ((row_group_operand == 2 && !transB) || (row_group_operand == 1 && transB)) return OMR_ERR_ARG;
@@ -480,4 +507,52 @@ extern "C" int omr_linear_wgrad_grouped(int dtype, int nprob, const omr_dw_probl
         OMR_CHECK_LAUNCH();
     }
     return OMR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp8 path (BASELINE config "fp8 MFMA weights"; an extension: the reference has no fp8).  Both operands are OCP e4m3 with one
+// fp32 scale per ROW (weights: per output feature, quantised once; activations: per token, quantised on the fly by
+// omr_quantize_rows_fp8), the products run on the fp8 MFMA, accumulation and the de-quantising epilogue are fp32.
+namespace {
+// one wave per row: absmax -> scale = absmax / 448 (e4m3 max) -> q = x / scale rounded to fp8 (RNE)
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const T* __restrict__ x, long ldx, fp8* __restrict__ q, long ldq, float* __restrict__ scale,
+                                                                int M, int K) {
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T* xr = x + row * ldx;
+    float mx = 0.f;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf(to_f32(xr[k])));
+    mx = wave_max(mx);
+    const float sc = mx > 0.f ? mx / 448.f : 1.f;
+    for (int k = lane; k < K; k += 64) q[row * ldq + k] = from_f32<fp8>(to_f32(xr[k]) / sc);      // true divisions: the codes equal torch's (x / scale).to(float8_e4m3fn)
+    if (lane == 0) scale[row] = sc;
+}
+}  // namespace
+
+extern "C" int omr_quantize_rows_fp8(int dtype, const void* x, long ldx, unsigned char* q, long ldq, float* scale, int M, int K, void* stream) {
+    if (M <= 0 || K <= 0 || !x || !q || !scale || ldx < K || ldq < K) return OMR_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == OMR_BF16) hipLaunchKernelGGL((quantize_rows_fp8_kernel<bf16>), cdiv(M, 4), 256, 0, s, (const bf16*)x, ldx, q, ldq, scale, M, K);
+    else if (dtype == OMR_F32) hipLaunchKernelGGL((quantize_rows_fp8_kernel<float>), cdiv(M, 4), 256, 0, s, (const float*)x, ldx, q, ldq, scale, M, K);
+    else return OMR_ERR_UNSUPPORTED;
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_gemm_fp8(int c_dtype, int M, int N, int K, const unsigned char* A8, long lda, const float* scale_a, const unsigned char* W8, long ldb,
+                            const float* scale_w, void* C, long ldc, const float* bias, int relu, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A8 || !W8 || !C || !scale_a || !scale_w) return OMR_ERR_ARG;
+    if (lda % 16 || ldb % 16 || ((uintptr_t)A8 & 15) || ((uintptr_t)W8 & 15)) return OMR_ERR_ARG;      // 16-byte aligned rows
+    GemmArgs g;
+    g.A = A8; g.B = W8; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.relu = relu; g.accum = 0; g.atomic = 0; g.colsum_a = nullptr; g.ksplit_len = cdiv(K, 128) * 128;
+    g.drop_thresh = 0; g.drop_scale = 1.f; g.drop_seed = 0;
+    g.grp = g.grp_stride = g.grp_base = g.grp_operand = 0;
+    g.scale_a = scale_a; g.scale_b = scale_w;
+    hipStream_t s = (hipStream_t)stream;
+    if (c_dtype == OMR_BF16) return launch<fp8, bf16>(g, 0, 0, 1, s);
+    if (c_dtype == OMR_F32) return launch<fp8, float>(g, 0, 0, 1, s);
+    return OMR_ERR_UNSUPPORTED;
 }

@@ -14,5 +14,7 @@ struct GemmArgs {
     // (index k), 3 = rows of C / entries of colsum_a (index m).  Lets ONE GEMM run over the K|V rows of all decoder layers'
     // packed in_proj matrices where they lie in the flat parameter buffer ([Wq;Wk;Wv] blocks back to back).
     int grp, grp_stride, grp_base, grp_operand;
+    // fp8 operands (omr_gemm_fp8): C = (A8 . B8^T) * scale_a[m] * scale_b[n] + bias -- per-row quantisation scales of both operands
+    const float* scale_a; const float* scale_b;
 };
 

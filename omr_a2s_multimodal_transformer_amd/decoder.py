@@ -300,10 +300,11 @@ class Decoder(nn.Module):
 
 class _DecodeDesc(ctypes.Structure):
     """omr_decode_desc of include/omr_hip.h."""
-    _fields_ = [(n, ctypes.c_int) for n in ("dtype", "B", "L", "d", "nhead", "ff", "V", "ldv", "max_len", "S", "window", "reserved")] + [
+    _fields_ = [(n, ctypes.c_int) for n in ("dtype", "B", "L", "d", "nhead", "ff", "V", "ldv", "max_len", "S", "window", "fp8")] + [
         ("emb", ctypes.c_void_p), ("pe", ctypes.c_void_p), ("layer_w", ctypes.c_void_p), ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p),
         ("self_kv", ctypes.c_void_p), ("cross_kv", ctypes.c_void_p), ("cross_ld", ctypes.c_long), ("cross_bs", ctypes.c_long),
-        ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_long)]
+        ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_long),
+        ("layer_w8", ctypes.c_void_p), ("layer_s8", ctypes.c_void_p), ("head_w8", ctypes.c_void_p), ("head_s8", ctypes.c_void_p)]
 
 
 class DecodeState:
@@ -315,6 +316,8 @@ class DecodeState:
                     "norm1.weight", "norm1.bias", "multihead_attn.in_proj_weight", "multihead_attn.in_proj_bias",
                     "multihead_attn.out_proj.weight", "multihead_attn.out_proj.bias", "norm2.weight", "norm2.bias",
                     "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias", "norm3.weight", "norm3.bias")
+    FP8_PARAMS = ("self_attn.in_proj_weight", "self_attn.out_proj.weight", "multihead_attn.in_proj_weight",
+                  "multihead_attn.out_proj.weight", "linear1.weight", "linear2.weight")          # OMR_DECODE_LAYER_FP8 order
 
     def __init__(self, dec: "Decoder", memory: torch.Tensor, dt: torch.dtype):
         layers = dec.transformer_decoder.layers
@@ -349,6 +352,21 @@ class DecodeState:
             ptrs += [pointer(named[n]) for n in self.LAYER_PARAMS]
         self._layer_w = (ctypes.c_void_p * len(ptrs))(*ptrs)
         self.pe = dec.pos_1d.pe[0].contiguous()
+        # fp8 mode (BASELINE config 5, an extension): every matrix of the step quantised ONCE to OCP e4m3 with a scale per
+        # output row; the executor quantises the activations per token and runs the fp8 MFMA GEMM (omr_gemm_fp8)
+        self.fp8 = bool(getattr(dec, "fp8_weights", False))
+        self._fp8 = []
+        if self.fp8:
+            def quantised(p):
+                w = Fn.wt(p, dt)
+                q, s = K.quantize_rows_fp8(w.view(w.shape[0], -1))
+                self._fp8.append((q, s))
+                return q.data_ptr(), s.data_ptr()
+
+            pairs = [quantised(dict(layer.named_parameters())[n]) for layer in layers for n in self.FP8_PARAMS]
+            self._layer_w8 = (ctypes.c_void_p * len(pairs))(*[a for a, _ in pairs])
+            self._layer_s8 = (ctypes.c_void_p * len(pairs))(*[b for _, b in pairs])
+            self._head8 = quantised(dec.out_layer.weight)
         self.desc = _DecodeDesc()
         self._bind()
 
@@ -357,7 +375,10 @@ class DecodeState:
         dec, ds = self.dec, self.desc
         ds.dtype, ds.B, ds.L, ds.d, ds.nhead = dtype_code(self.dtype), self.B, self.L, self.d, dec.transformer_decoder.layers[0].self_attn.num_heads
         ds.ff, ds.V, ds.ldv, ds.max_len, ds.S = dec.transformer_decoder.layers[0].linear1.weight.shape[0], self.V, self.ldv, self.max_len, self.S
-        ds.window, ds.reserved = (dec.attn_window if dec.attn_window > 0 else -1), 0
+        ds.window, ds.fp8 = (dec.attn_window if dec.attn_window > 0 else -1), int(self.fp8)
+        if self.fp8:
+            ds.layer_w8, ds.layer_s8 = ctypes.cast(self._layer_w8, ctypes.c_void_p), ctypes.cast(self._layer_s8, ctypes.c_void_p)
+            ds.head_w8, ds.head_s8 = self._head8
         ds.emb, ds.pe = Fn.wt(dec.embedding.weight, self.dtype).data_ptr(), self.pe.data_ptr()
         ds.layer_w = ctypes.cast(self._layer_w, ctypes.c_void_p)
         ds.head_w, ds.head_b = Fn.wt(dec.out_layer.weight, self.dtype).data_ptr(), dec.out_layer.bias.omr_phys.data_ptr()

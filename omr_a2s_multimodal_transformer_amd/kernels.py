@@ -102,6 +102,34 @@ def linear_wgrad_grouped(problems) -> None:
     lib().call("omr_linear_wgrad_grouped", dtype_code(dt), len(problems), ctypes.byref(arr), cur_stream())
 
 
+def quantize_rows_fp8(x: Tensor) -> Tuple[Tensor, Tensor]:
+    """x [M, K] (fp32 / bf16, unit inner stride) -> (OCP e4m3 codes uint8 [M, K], fp32 scale per row [M]): x ~ codes * scale."""
+    require_cuda(x)
+    M, K, ld = _rows2d(x)
+    q = torch.empty((M, (K + 15) // 16 * 16), dtype=torch.uint8, device=x.device)
+    if q.shape[1] != K:
+        q.zero_()                                # padded k columns must read as fp8 zeros
+    scale = torch.empty(M, dtype=torch.float32, device=x.device)
+    lib().call("omr_quantize_rows_fp8", dtype_code(x.dtype), ptr(x), ld, ptr(q), q.stride(0), ptr(scale), M, K, cur_stream())
+    return q, scale
+
+
+def gemm_fp8(a8: Tensor, scale_a: Tensor, w8: Tensor, scale_w: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
+             out_dtype: torch.dtype = torch.bfloat16, out: Optional[Tensor] = None) -> Tensor:
+    """C[M, N] = (a8 . w8^T) * scale_a[m] * scale_w[n] + bias on the fp8 MFMA (a8 [M, K], w8 [N, K]: quantize_rows_fp8 outputs)."""
+    require_cuda(a8, w8, scale_a, scale_w, bias, out)
+    assert a8.dtype == w8.dtype == torch.uint8 and a8.shape[1] == w8.shape[1] and a8.stride(1) == w8.stride(1) == 1
+    M, K = a8.shape
+    N = w8.shape[0]
+    assert scale_a.numel() == M and scale_w.numel() == N and scale_a.dtype == scale_w.dtype == torch.float32
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a8.device)
+    assert tuple(out.shape) == (M, N) and out.stride(1) == 1
+    lib().call("omr_gemm_fp8", dtype_code(out.dtype), M, N, K, ptr(a8), a8.stride(0), ptr(scale_a), ptr(w8), w8.stride(0), ptr(scale_w), ptr(out),
+               out.stride(0), ptr(bias), int(relu), cur_stream())
+    return out
+
+
 def cast(x: Tensor, dtype: torch.dtype, out: Optional[Tensor] = None) -> Tensor:
     require_cuda(x)
     assert x.is_contiguous()

@@ -107,9 +107,11 @@ class _Base(FlatModuleMixin, LightningModule):
 
     def _make_decoder(self) -> Decoder:
         c = self.config
-        return Decoder(output_size=len(self.w2i), max_seq_len=self.max_seq_len, num_embeddings=len(self.w2i), embedding_dim=c.d_model,
-                       padding_idx=self.padding_idx, ff_dim=c.ff_dim, dropout_p=c.dropout, nhead=c.nhead,
-                       num_transformer_layers=c.num_layers, attn_window=self.attn_window)
+        dec = Decoder(output_size=len(self.w2i), max_seq_len=self.max_seq_len, num_embeddings=len(self.w2i), embedding_dim=c.d_model,
+                      padding_idx=self.padding_idx, ff_dim=c.ff_dim, dropout_p=c.dropout, nhead=c.nhead,
+                      num_transformer_layers=c.num_layers, attn_window=self.attn_window)
+        dec.fp8_weights = bool(c.fp8_decode)         # KV-cached decoding on the fp8 MFMA (decoder.DecodeState)
+        return dec
 
     # ---- data parallel (ddp.py): bucket boundaries are autograd nodes placed where a bucket's gradients are final
     _reducer = None

@@ -196,6 +196,74 @@ def test_grouped_linear_weight_gradients_match_torch(dtype):
     assert ((probs[-1][3].double().cpu() - want_b).norm() / want_b.norm()).item() < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fp8_row_quantisation_and_fp8_mfma_gemm(dtype):
+    """fp8 path (BASELINE config 5; the reference has no fp8, so the checker is torch's own float8_e4m3fn): the row
+    quantiser reproduces scale = absmax / 448 and torch's round-to-nearest e4m3 codes; the fp8-MFMA GEMM equals the fp64
+    product of the DE-QUANTISED operands (only the accumulation order differs) and is within fp8 rounding of the unquantised
+    product."""
+    from omr_a2s_multimodal_transformer_amd import kernels as K
+    g = torch.Generator().manual_seed(11)
+    for M, N, Kd in ((5, 256, 256), (130, 6997, 256), (64, 768, 128), (1, 256, 256)):
+        x = (torch.randn((M, Kd), generator=g) * 1.7).to(dtype)
+        w = (torch.randn((N, Kd), generator=g) * 0.06).to(dtype)
+        bias = torch.randn(N, generator=g) * 0.1
+        x8, sx = K.quantize_rows_fp8(x.to(DEV))
+        w8, sw = K.quantize_rows_fp8(w.to(DEV))
+        for t, q, s in ((x, x8, sx), (w, w8, sw)):
+            ref_s = t.float().abs().amax(dim=1) / 448.0
+            torch.testing.assert_close(s.cpu(), ref_s, rtol=1e-6, atol=0)
+            ref_q = (t.float() / ref_s[:, None]).to(torch.float8_e4m3fn)
+            same = (q.cpu().view(torch.float8_e4m3fn).float() == ref_q.float()).float().mean().item()
+            assert same > 0.999, same                       # ties of the division's last bit may round the other way
+        deq = lambda q, s: q.cpu().view(torch.float8_e4m3fn).double() * s.cpu().double()[:, None]
+        ref = deq(x8, sx) @ deq(w8, sw).t() + bias.double()
+        for relu in (False, True):
+            out = K.gemm_fp8(x8, sx, w8, sw, bias=bias.to(DEV), relu=relu, out_dtype=torch.float32)
+            want = ref.clamp_min(0) if relu else ref
+            assert ((out.double().cpu() - want).norm() / want.norm()).item() < 1e-4      # fp32 accumulation order + fp32 scale products
+        out16 = K.gemm_fp8(x8, sx, w8, sw, bias=bias.to(DEV), out_dtype=torch.bfloat16)
+        assert ((out16.double().cpu() - ref).norm() / ref.norm()).item() < 5e-3
+        full = x.double() @ w.double().t() + bias.double()
+        assert ((ref - full).norm() / full.norm()).item() < 6e-2              # what e4m3 costs (3 mantissa bits on both operands)
+
+
+def test_fp8_decode_tracks_the_bf16_decode():
+    """Greedy decoding with fp8 MFMA weights (ModelConfig.fp8_decode): the per-step logits stay close to the bf16 decode fed
+    with the same tokens, and a run of tokens from one host call equals the single steps of the fp8 mode."""
+    from omr_a2s_multimodal_transformer_amd import kernels as K
+    from omr_a2s_multimodal_transformer_amd.model import Transformer
+    V = 40
+    w2i, i2w = syn.make_vocab(V)
+    models = {}
+    for fp8 in (False, True):
+        m = Transformer(32, 96, 20, w2i, i2w, config=ModelConfig(num_layers=3, compute_dtype="bf16", fp8_decode=fp8)).eval()
+        load(m, syn.transformer_shapes(V, layers=3), 61)
+        m.flatten_parameters()
+        models[fp8] = m
+    x = rnd((2, 1, 32, 96), 702).to(DEV)
+    mem = models[False].encode(x)
+    st16, st8 = models[False].decoder.init_decode(mem), models[True].decoder.init_decode(mem)
+    assert st8.fp8 and not st16.fp8
+    tok = torch.full((2, 1), w2i["<sos>"], dtype=torch.int64, device=DEV)
+    for _ in range(6):
+        l16 = models[False].decoder.decode_step(tok, st16).clone()
+        l8 = models[True].decoder.decode_step(tok, st8).clone()
+        assert torch.isfinite(l8).all()
+        assert ((l8 - l16).norm() / l16.norm()).item() < 0.15
+        tok = K.argmax(l16.contiguous())[0].view(2, 1)
+    st_a, st_b = models[True].decoder.init_decode(mem), models[True].decoder.init_decode(mem)
+    tok0 = torch.full((2, 1), w2i["<sos>"], dtype=torch.int64, device=DEV)
+    toks, _ = models[True].decoder.decode_tokens(tok0, st_a, 5)
+    t = tok0
+    for i in range(5):
+        idx, _ = K.argmax(models[True].decoder.decode_step(t, st_b).contiguous())
+        assert torch.equal(idx, toks[i])
+        t = idx.view(2, 1)
+    words, _ = models[True]._greedy(mem[:1].contiguous())
+    assert len(words) >= 1
+
+
 @pytest.mark.parametrize("dtype,win,B", [("fp32", -1, 1), ("fp32", 3, 3), ("bf16", -1, 2)])
 def test_native_decode_runs_of_tokens_equal_single_steps(dtype, win, B):
     """omr_decode_steps: n positions from ONE host call (token chained on the device) give exactly the tokens, top-1 logits
