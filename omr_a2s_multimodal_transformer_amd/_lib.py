@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(REPO_ROOT, "include", "omr_hip.h")
-LIB_PATH = os.path.join(_HERE, "libomr_hip.so")
+LIB_PATH = os.environ.get("OMR_HIP_LIB") or os.path.join(_HERE, "libomr_hip.so")   # OMR_HIP_LIB: another build of the same ABI (kernel experiments)
 
 F32, BF16 = 0, 1
 _DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}

@@ -62,9 +62,10 @@ struct ConvArgs {
 // registers are 4 runs of 4 consecutive couts: bias/ReLU in registers, one 8-byte LDS store per run, then the tile
 // leaves LDS as 16-byte row-contiguous global stores (direct 8-byte global stores were measured 15 % slower).
 // EPI selects the fused-epilogue code that is compiled in (keeps the plain kernel's register footprint small):
-//   0 plain | 1 forward extras: MixDropout + InstanceNorm statistics of the output | 2 backward extras: InstanceNorm-backward sums
+//   0 plain | 1 forward: InstanceNorm statistics of the output | 2 backward: InstanceNorm-backward sums | 3 forward: MixDropout (+ statistics)
+// (one kernel with the MixDropout code behind a run-time test was measured 7-10 % slower on the statistics-only launches, two steps in three)
 template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, bool SINGLE, int EPI>
-__global__ __launch_bounds__(256, (SINGLE && NT == 32) ? (CK == 16 ? 4 : 3) : 2) void conv3x3_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2) ? 4 : 3) : 2) void conv3x3_mfma_kernel(ConvArgs a) {
     typedef typename Frag<T>::type F;
     typedef __attribute__((ext_vector_type(4))) T T4;
     constexpr int VEC = Frag<T>::N;
@@ -124,33 +125,39 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? (CK == 16 ? 4 : 3) : 2)
     // fused reductions: this thread always stores the same VEC-channel chunk, so it keeps fp32 partials in registers; when the
     // block is done with its (single) image the partials are combined in a FIXED order through LDS (the staging tiles are
     // dead by then) and stored into the block's own slot of the fp64 workspace -- bit-identical from run to run.
+    // (Summing in the accumulator-to-LDS pass instead -- a lane holds 16 couts of its pixels there, as fp32 -- was measured:
+    // 32 partial-sum registers per lane push the 16/32-channel variants over their occupancy budget, 591 -> 682 us.)
     constexpr int CPO = NT / VEC;
     constexpr int NSV = EPI ? VEC : 1;
-    float ssum[NSV], ssq[NSV], smu[NSV], srs[NSV];
+    float ssum[NSV], ssq[NSV], smu[EPI == 2 ? VEC : 1], srs[EPI == 2 ? VEC : 1];
 #pragma unroll
-    for (int e = 0; e < NSV; ++e) { ssum[e] = ssq[e] = 0.f; smu[e] = 0.f; srs[e] = 1.f; }
-    const bool stat1 = EPI == 1 && a.stat_mode == 1, stat2 = EPI == 2 && a.stat_mode == 2;
+    for (int e = 0; e < NSV; ++e) ssum[e] = ssq[e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < (EPI == 2 ? VEC : 1); ++e) { smu[e] = 0.f; srs[e] = 1.f; }
+    constexpr bool FWD = EPI == 1 || EPI == 3, DROP = EPI == 3;     // forward extras; MixDropout code compiled in
+    const bool stat1 = FWD && a.stat_mode == 1, stat2 = EPI == 2 && a.stat_mode == 2;
     auto flush_stats = [&](int bimg) {
         if constexpr (EPI != 0) {
             constexpr int NGRP = 256 / CPO;                       // threads that share a channel chunk
-            static_assert((size_t)NGRP * 2 * NT * sizeof(float) <= ((size_t)XS_ELEMS + (size_t)NT * 9 * CKP) * sizeof(T), "reduction scratch fits in the (dead) halo + weight tiles");
-            float* red = reinterpret_cast<float*>(smem_raw);      // [NGRP][NT][2]
-            __syncthreads();                                      // the last tile's store loop is done with Os
-            const int kcs = (tid % CPO) * VEC, grp = tid / CPO;
+            constexpr int RP = NT + 1;                             // odd pitch: the lanes of a wave write one column
+            static_assert((size_t)NGRP * RP * sizeof(float) <= ((size_t)XS_ELEMS + (size_t)NT * 9 * CKP) * sizeof(T), "reduction scratch fits in the (dead) halo + weight tiles");
+            float* red = reinterpret_cast<float*>(smem_raw);      // [NGRP][RP], first the sums, then the second moments
 #pragma unroll
-            for (int e = 0; e < NSV; ++e) {
-                red[(grp * NT + kcs + e) * 2] = ssum[e];
-                red[(grp * NT + kcs + e) * 2 + 1] = ssq[e];
-            }
-            __syncthreads();
-            for (int i = tid; i < 2 * NT; i += 256) {
-                const int n = n0 + (i >> 1);
-                double acc2 = 0.0;
-                for (int g = 0; g < NGRP; ++g) acc2 += (double)red[g * 2 * NT + i];
-                if (n < a.COUT) {
-                    a.stat_ws[(((long)bimg * a.stat_slots + blockIdx.x) * a.COUT + n) * 2 + (i & 1)] = acc2;
-                    if (blockIdx.x == 0)          // slots no block of this launch owns read as zero: the caller need not clear the workspace
-                        for (int k = gridDim.x; k < a.stat_slots; ++k) a.stat_ws[(((long)bimg * a.stat_slots + k) * a.COUT + n) * 2 + (i & 1)] = 0.0;
+            for (int k = 0; k < 2; ++k) {
+                __syncthreads();                                  // the last tile's store loop is done with Os / pass 0 has been read
+                const int kcs = (tid % CPO) * VEC, grp = tid / CPO;
+#pragma unroll
+                for (int e = 0; e < NSV; ++e) red[grp * RP + kcs + e] = k ? ssq[e] : ssum[e];
+                __syncthreads();
+                for (int i = tid; i < NT; i += 256) {
+                    const int n = n0 + i;
+                    double acc2 = 0.0;
+                    for (int g = 0; g < NGRP; ++g) acc2 += (double)red[g * RP + i];
+                    if (n < a.COUT) {
+                        a.stat_ws[(((long)bimg * a.stat_slots + blockIdx.x) * a.COUT + n) * 2 + k] = acc2;
+                        if (blockIdx.x == 0)          // slots no block of this launch owns read as zero: the caller need not clear the workspace
+                            for (int sl = gridDim.x; sl < a.stat_slots; ++sl) a.stat_ws[(((long)bimg * a.stat_slots + sl) * a.COUT + n) * 2 + k] = 0.0;
+                    }
                 }
             }
         }
@@ -161,12 +168,33 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? (CK == 16 ? 4 : 3) : 2)
     // (its fused-reduction partials are flushed once, at the end)
     const int tiles_per_img = a.tiles_h * a.tiles_w;
     const int b = blockIdx.z;
-    if (stat2) {
+    if constexpr (EPI == 2) {
+        if (stat2) {
 #pragma unroll
-        for (int e = 0; e < NSV; ++e) {
-            const int n = n0 + (tid % CPO) * VEC + e;
-            smu[e] = n < a.COUT ? a.stat_mean[(long)b * a.COUT + n] : 0.f;
-            srs[e] = n < a.COUT ? a.stat_rstd[(long)b * a.COUT + n] : 1.f;
+            for (int e = 0; e < VEC; ++e) {
+                const int n = n0 + (tid % CPO) * VEC + e;
+                smu[e] = n < a.COUT ? a.stat_mean[(long)b * a.COUT + n] : 0.f;
+                srs[e] = n < a.COUT ? a.stat_rstd[(long)b * a.COUT + n] : 1.f;
+            }
+        }
+    }
+    // EPI 3, channel-wise MixDropout (Dropout2d): the keep decision depends on (image, cout) only, so the 16 NB decisions of
+    // this lane's couts are taken once per block -- bit r of ckeep[j] belongs to accumulator register r of cout block j
+    // (same pair hash as omr_dropout: index (b * COUT + n), one hash per even/odd cout pair).
+    uint32_t ckeep[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) ckeep[j] = 0xffffu;
+    if constexpr (DROP) {
+        if (a.drop_thresh && a.drop_channel) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                ckeep[j] = 0;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const uint32_t hsh = drop_pair_bits(a.drop_seed, ((uint64_t)b * a.COUT + n0 + j * 32 + 8 * (r >> 2) + hsel + (r & 3)) >> 1);
+                    ckeep[j] |= (uint32_t)((hsh & 0xffffu) >= a.drop_thresh) << r | (uint32_t)((hsh >> 16) >= a.drop_thresh) << (r + 1);
+                }
+            }
         }
     }
     // Staging registers.  PF (every multi-chunk variant: those are LDS-limited to two workgroups per CU, so the registers are
@@ -301,8 +329,11 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? (CK == 16 ? 4 : 3) : 2)
             }
         }
 
-        // ---- epilogue
+        // ---- epilogue.  Channel-wise MixDropout is applied here from the block's ckeep bits; the elementwise kind hashes in
+        //      the store loop, where the accumulators are dead (registers).  (Starting the accumulator chains from the bias
+        //      instead of adding it here was measured: 483 -> 523 us on the plain 32-channel kernel.)
         const float oscale = a.mask ? a.mask_scale : 1.f;
+        const bool drop_chan = DROP && a.drop_thresh != 0 && a.drop_channel;
         __syncthreads();                              // every wave is done reading Xs: Os aliases it
 #pragma unroll
         for (int j = 0; j < NB; ++j)
@@ -312,12 +343,18 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? (CK == 16 ? 4 : 3) : 2)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     T4 o;
+                    const uint32_t k4 = ckeep[j] >> (4 * g);
                     const f32x4 bq = *reinterpret_cast<const f32x4*>(&sbias[j * 32 + 8 * g + hsel]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float v = acc[i][j][4 * g + e] + bq[e];
                         if (a.relu) v = fmaxf(v, 0.f);
-                        o[e] = from_f32<T>(v * oscale);     // the epilogue mask's 1/(1-p) rides here in fp32: the store loop only selects
+                        if constexpr (DROP) {
+                            if (drop_chan) v = ((k4 >> e) & 1u) ? v * a.drop_scale : 0.f;
+                        } else {
+                            v *= oscale;                    // the epilogue mask's 1/(1-p) rides here in fp32: the store loop only selects
+                        }
+                        o[e] = from_f32<T>(v);
                     }
                     *reinterpret_cast<T4*>(orow + 8 * g) = o;
                 }
@@ -326,7 +363,6 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? (CK == 16 ? 4 : 3) : 2)
         T* Y = (T*)a.y + (long)b * a.Ho * a.Wo * a.COUT;
         const T* Mk = a.mask ? (const T*)a.mask + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
         const T* SX = stat2 ? (const T*)a.stat_x + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
-        const uint64_t img_base = (uint64_t)b * a.Ho * a.Wo * a.COUT;
 #pragma unroll(EPI == 0 ? 8 : 4)
         for (int c = tid; c < TH * TW * CPO; c += 256) {
             const int pl = c / CPO, kc = (c % CPO) * VEC;
@@ -334,13 +370,12 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? (CK == 16 ? 4 : 3) : 2)
             if (oh >= a.Ho || ow >= a.Wo || n >= a.COUT) continue;
             F v = *reinterpret_cast<const F*>(Os + (long)pl * OP + kc);
             const long o = ((long)oh * a.Wo + ow) * a.COUT + n;
-            if constexpr (EPI == 1) {
-                if (a.drop_thresh) {   // MixDropout after the ReLU, keyed exactly like omr_dropout (flat NHWC index / (image, channel))
-                    // drop_keep() of the VEC consecutive indices base .. base + VEC - 1: ONE hash per element pair (16 random bits
-                    // each), with the index folding hoisted -- base is a multiple of VEC (COUT % VEC == 0), so the pair indices are
-                    // (base >> 1) ^ e in the low word and share the high word
-                    const uint64_t pbase = (a.drop_channel ? (uint64_t)b * a.COUT + n : img_base + (uint64_t)o) >> 1;
-                    const uint32_t h0 = (uint32_t)pbase ^ (uint32_t)(pbase >> 32) * 0x27D4EB2Fu;
+            if constexpr (DROP) {
+                if (a.drop_thresh && !a.drop_channel) {   // elementwise MixDropout after the ReLU, keyed exactly like omr_dropout by the flat NHWC index:
+                    // drop_keep() of the VEC consecutive indices base .. base + VEC - 1, ONE hash per element pair (16 random bits
+                    // each); base is a multiple of VEC (COUT % VEC == 0), so the pair indices are (base >> 1) + e
+                    const uint64_t pbase = ((uint64_t)b * a.Ho * a.Wo * a.COUT + (uint64_t)o) >> 1;      // a multiple of VEC / 2: "+ e" is "^ e"
+                    const uint32_t h0 = (uint32_t)pbase ^ (uint32_t)(pbase >> 32) * 0x27D4EB2Fu;          // drop_pair_bits() with the index folding hoisted
                     const uint32_t slo = (uint32_t)a.drop_seed, shi = (uint32_t)(a.drop_seed >> 32);
 #pragma unroll
                     for (int e = 0; e < VEC / 2; ++e) {
@@ -361,7 +396,7 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? (CK == 16 ? 4 : 3) : 2)
                 __builtin_memcpy(&v, &bits, sizeof(bits));
             }
             *reinterpret_cast<F*>(Y + o) = v;
-            if constexpr (EPI == 1) {
+            if constexpr (FWD) {
                 if (stat1) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) { const float f = to_f32(v[e]); ssum[e] += f; ssq[e] += f * f; }
@@ -424,10 +459,14 @@ template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, b
 template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, bool SINGLE> int launch_conv2(const ConvArgs& a, hipStream_t s) {
     constexpr bool can1 = (DH == 1 && DW == 1), can2 = (SH == 1 && SW == 1);
     constexpr bool is_f32 = std::is_same<T, float>::value;
-    int epi = (a.stat_mode == 2) ? 2 : ((a.drop_thresh || a.stat_mode == 1) ? 1 : 0);
+    int epi = (a.stat_mode == 2) ? 2 : (a.drop_thresh ? 3 : (a.stat_mode == 1 ? 1 : 0));
     if (is_f32 && epi == 0) epi = can1 ? 1 : 2;
     if (epi == 1) {
         if constexpr (can1) return launch_conv3<T, NT, RPW, CK, SH, SW, DH, DW, SINGLE, 1>(a, s);
+        else return OMR_ERR_UNSUPPORTED;
+    }
+    if (epi == 3) {
+        if constexpr (can1) return launch_conv3<T, NT, RPW, CK, SH, SW, DH, DW, SINGLE, 3>(a, s);
         else return OMR_ERR_UNSUPPORTED;
     }
     if (epi == 2) {

@@ -410,13 +410,20 @@ __global__ __launch_bounds__(256) void gemm_dw_grouped_kernel(DwGroup grp) {
 
 template <typename T, typename TC> int launch(GemmArgs g, int ta, int tb, int splits, hipStream_t s) {
     g.nt = cdiv(g.N, BN); g.mt = cdiv(g.M, BM);
-    const bool fullk = !ta && splits == 1 && g.K <= 4 * GemmCfg<T>::BK;
+    // FULLK keeps all four k-slabs of both operands in staging registers: fine for 2- and 4-byte elements, 42-75 spilled
+    // registers with fp8's 16-element chunks -- the fp8 GEMMs take the pipelined loop.
+    constexpr bool CAN_FULLK = !std::is_same<T, fp8>::value;
+    const bool fullk = CAN_FULLK && !ta && splits == 1 && g.K <= 4 * GemmCfg<T>::BK;
     g.total = g.nt * g.mt * splits;
     g.chunk = splits > 1 ? g.nt * g.mt : g.nt;
     const int nchunks = g.total / g.chunk;
     dim3 grid((unsigned)(cdiv(nchunks, 8) * 8 * g.chunk)), block(256);
-    if (!ta && !tb && fullk) hipLaunchKernelGGL((gemm_kernel<T, TC, false, false, true>), grid, block, 0, s, g);
-    else if (!ta && tb && fullk) hipLaunchKernelGGL((gemm_kernel<T, TC, false, true, true>), grid, block, 0, s, g);
+    bool done = false;
+    if constexpr (CAN_FULLK) {
+        if (!ta && !tb && fullk) { hipLaunchKernelGGL((gemm_kernel<T, TC, false, false, true>), grid, block, 0, s, g); done = true; }
+        else if (!ta && tb && fullk) { hipLaunchKernelGGL((gemm_kernel<T, TC, false, true, true>), grid, block, 0, s, g); done = true; }
+    }
+    if (done) {}
     else if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, TC, false, false, false>), grid, block, 0, s, g);
     else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, TC, false, true, false>), grid, block, 0, s, g);
     else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, TC, true, false, false>), grid, block, 0, s, g);

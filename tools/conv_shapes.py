@@ -43,9 +43,11 @@ def main():
             st_in = K.instnorm_stats(x)
             t_n = timeit(lambda: K.conv3x3(x, w, bias, stride=st, relu=True, in_stats=st_in), 10)
         ideal = mb / 4.0
+        gf = 2.0 * B * Ho * Wo * co * ci * 9 / 1e9
+        floor = max(mb / 6.3, gf / 1.2)            # us: HBM at the achievable 6.3 TB/s | MFMA at the ~1.2 PF/s a tuned bf16 loop holds
         for i, t in enumerate((ideal, t_f, t_d, t_w)):
             tot[i] += t
-        print(f"{name:8s} {mb:6.0f} {ideal:14.0f} | {t_f:7.0f} {t_d:7.0f} {t_w:7.0f}" + (f"   fwd with IN-apply {t_n:5.0f}" if t_n else ""), flush=True)
+        print(f"{name:8s} {mb:6.0f} {ideal:14.0f} | {t_f:7.0f} {t_d:7.0f} {t_w:7.0f}" + f"  | {gf:5.0f} GF floor {floor:4.0f} us  fwd x{t_f / floor:4.2f} dgrad x{t_d / floor:4.2f}" + (f"   fwd with IN-apply {t_n:5.0f}" if t_n else ""), flush=True)
     print("totals (ms): ideal %.2f fwd %.2f dgrad %.2f wgrad %.2f" % tuple(t / 1e3 for t in tot))
 
 

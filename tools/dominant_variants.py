@@ -10,12 +10,14 @@ x = torch.rand((B, H, W, C), device="cuda").to(torch.bfloat16)
 w = (torch.rand((C, 3, 3, C), device="cuda") - 0.5).to(torch.bfloat16)
 bias = torch.zeros(C, device="cuda")
 ws, slots = K.conv_stat_ws(B, H, W, C, x.device)
+st = K.instnorm_stats(x)
 variants = {
     "plain (EPI=0)": lambda: K.conv3x3(x, w, bias, relu=True),
     "stats (EPI=1)": lambda: K.conv3x3(x, w, bias, relu=True, stat_mode=1, stat_ws=ws, stat_slots=slots),
     "stats + elementwise dropout": lambda: K.conv3x3(x, w, bias, relu=True, drop=(0.5, 7, False), stat_mode=1, stat_ws=ws, stat_slots=slots),
     "stats + channel dropout": lambda: K.conv3x3(x, w, bias, relu=True, drop=(0.25, 7, True), stat_mode=1, stat_ws=ws, stat_slots=slots),
     "masked dgrad (EPI=0 + mask)": lambda: K.conv3x3(x, w, None, out_mask=x, mask_scale=2.0),
+    "dgrad + IN-backward sums (EPI=2)": lambda: K.conv3x3(x, w, None, stat_mode=2, stat_ws=ws, stat_slots=slots, stat_x=x, stat_stats=st),
 }
 gb = B * H * W * 2 * C * 2 / 1e9
 for name, fn in variants.items():
