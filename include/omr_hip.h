@@ -205,6 +205,12 @@ long omr_attn_split_workspace_floats(int B, int H, int T, int S, int head_dim);
 int omr_attn_fwd_split(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                        long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, const float* key_bias,
                        float* split_ws, long split_ws_floats, void* stream);
+/* omr_attn_fwd_split without its merge pass (decode: the out-projection merges while it loads its input rows).  *nsplit > 1:
+ * `o` is not written and split_ws holds, for (b, h, split j), head_dim un-normalised outputs + the running max (log2 domain)
+ * + the sum at ((b*H + h)*nsplit + j)*T*(head_dim + 2); *nsplit = 1: `o` holds the finished rows. */
+int omr_attn_fwd_split_partials(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv,
+                                long ldo, long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, float* split_ws,
+                                long split_ws_floats, int* nsplit, void* stream);
 /* Test / debug entry: the attention-probability dropout keep-mask (1 = kept) that omr_attn_fwd / omr_attn_bwd regenerate on
  * the fly for (seed, dropout_p), one byte per score, mask[B][H][T][S].  Lets a checker inject the very same mask into a CPU
  * restatement of nn.MultiheadAttention's dropout (tests/test_dropout_parity_gpu.py). */
@@ -244,6 +250,25 @@ typedef struct omr_decode_desc {
     const unsigned char* const* layer_w8; const float* const* layer_s8; const unsigned char* head_w8; const float* head_s8;
 } omr_decode_desc;
 long omr_decode_workspace_bytes(const omr_decode_desc* desc);
+/* One linear layer of a decode position, y[m][n] = act(sum_k x[m][k] * w[n][k] + bias[n]) for a handful of rows (M = batch rows
+ * of ONE position), with the element-wise kernel that would precede it folded into the loading of x (`pro`):
+ *   0  x = rows of `x` (ld ldx)
+ *   1  x = LayerNorm(y_prev + res) * gamma + beta   (nn.TransformerDecoderLayer norm1/2/3, decoder.py:86-95; y_prev = `x`)
+ *   2  x = embedding[tokens[m]] + pe_row            (decoder.py:124 at one position)
+ *   3  x = the merged key-split attention partials of omr_attn_fwd_split_partials (part, nsplit, H, hd; K = H * hd)
+ * Prologues 1 and 2 also store the rows they build to xn_out [M][K] (the residual input of the next sub-layer).  Columns
+ * [0, n0) go to out0 (ld0), the rest to out1 (ld1) -- a q | k|v projection writes its k|v part straight into the cache row;
+ * out32 (nullable, ld32): fp32 copy of the value rounded to `dtype` (the vocabulary head's logits).  Each (row, column) is
+ * a fixed-order fp32 sum that does not depend on M: a batched step reproduces the single-row step to the bit.
+ * Requires K % 64 == 0 for prologues 1-3, K <= 2048, 16-byte aligned weight rows. */
+typedef struct omr_decode_linear_args {
+    int dtype, pro, M, N, K, relu, n0, nsplit, H, hd, vocab, pad_;
+    float eps, pad2_;
+    const void* x; long ldx; const void* res; long ldres; const float* gamma; const float* beta; void* xn_out;
+    const long* tokens; const void* emb; const float* pe_row; const float* part;
+    const void* w; const float* bias; void* out0; long ld0; void* out1; long ld1; float* out32; long ld32;
+} omr_decode_linear_args;
+int omr_decode_linear(const omr_decode_linear_args* args, void* stream);
 int omr_decode_steps(const omr_decode_desc* desc, long* tokens, int t0, int n_steps, long* out_tokens, float* out_top1, float* last_logits,
                      void* stream);
 

@@ -721,10 +721,10 @@ __global__ void attn_dropout_mask_kernel(unsigned char* __restrict__ out, AttnAr
     }
 }
 
-template <typename T, int HD> int run_fwd(const AttnArgs& a, hipStream_t s) {
+template <typename T, int HD> int run_fwd(const AttnArgs& a, hipStream_t s, bool merge = true) {
     if (a.T <= 32 && a.S > 64) {        // a single 32-row query block: split the keys over the waves (and, with a workspace, over workgroups)
         hipLaunchKernelGGL((attn_fwd_kernel<T, HD, true>), dim3(a.nsplit > 1 ? a.nsplit : 1, a.H, a.B), dim3(256), 0, s, a);
-        if (a.nsplit > 1) hipLaunchKernelGGL((attn_split_merge_kernel<T, HD>), dim3(a.B * a.H * a.T), dim3(64), 0, s, a);
+        if (a.nsplit > 1 && merge) hipLaunchKernelGGL((attn_split_merge_kernel<T, HD>), dim3(a.B * a.H * a.T), dim3(64), 0, s, a);
         OMR_CHECK_LAUNCH();
         return OMR_OK;
     }
@@ -811,7 +811,7 @@ extern "C" long omr_attn_workspace_floats(int B, int H, int T, int S, int head_d
 static int attn_fwd_impl(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                          long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
                          const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed,
-                         float* split_ws, long split_ws_floats, void* stream);
+                         float* split_ws, long split_ws_floats, void* stream, int* nsplit_out = nullptr);
 
 /* omr_attn_fwd with caller-provided scratch for the key split (omr_attn_workspace_floats(..., backward = 0) floats) */
 extern "C" int omr_attn_fwd_ws(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
@@ -850,7 +850,7 @@ extern "C" int omr_attn_fwd_split(int dtype, const void* q, const void* k, const
 static int attn_fwd_impl(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                          long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
                          const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed,
-                         float* split_ws, long split_ws_floats, void* stream) {
+                         float* split_ws, long split_ws_floats, void* stream, int* nsplit_out) {
     AttnArgs a = {};
     int rc = fill_common(a, B, H, T, S, head_dim, dropout_p, seed, causal, window, key_bias, blk_lq, blk_lkv);
     if (rc) return rc;
@@ -868,9 +868,23 @@ static int attn_fwd_impl(int dtype, const void* q, const void* k, const void* v,
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == OMR_BF16) return head_dim == 64 ? run_fwd<bf16, 64>(a, s) : run_fwd<bf16, 32>(a, s);
-    if (dtype == OMR_F32) return head_dim == 64 ? run_fwd<float, 64>(a, s) : run_fwd<float, 32>(a, s);
+    const bool merge = nsplit_out == nullptr;           // a caller that asks for the split count merges the partials itself
+    if (nsplit_out) *nsplit_out = (T <= 32 && S > 64) ? a.nsplit : 1;
+    if (!merge && !(T <= 32 && S > 64)) { a.nsplit = 1; a.split_len = 0; a.part = nullptr; }
+    if (dtype == OMR_BF16) return head_dim == 64 ? run_fwd<bf16, 64>(a, s, merge) : run_fwd<bf16, 32>(a, s, merge);
+    if (dtype == OMR_F32) return head_dim == 64 ? run_fwd<float, 64>(a, s, merge) : run_fwd<float, 32>(a, s, merge);
     return OMR_ERR_UNSUPPORTED;
+}
+
+/* omr_attn_fwd_split WITHOUT the merge pass: when the keys were split (*nsplit > 1) `o` is not written and split_ws holds, per
+ * (b, h, split j), head_dim un-normalised outputs + running max (log2 domain) + sum at ((b*H + h)*nsplit + j)*T*(head_dim+2);
+ * the consumer merges them (omr_decode_linear, prologue 3).  *nsplit = 1: `o` holds the finished rows. */
+extern "C" int omr_attn_fwd_split_partials(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv,
+                                           long ldo, long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim,
+                                           float* split_ws, long split_ws_floats, int* nsplit, void* stream) {
+    if (T > 32 || !nsplit) return OMR_ERR_ARG;
+    return attn_fwd_impl(dtype, q, k, v, o, lse, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, T, S, head_dim, 0, -1, nullptr, nullptr, nullptr, 0.f, 0,
+                         split_ws, split_ws_floats, stream, nsplit);
 }
 
 extern "C" int omr_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,

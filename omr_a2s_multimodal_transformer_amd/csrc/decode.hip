@@ -7,13 +7,15 @@
 // chosen token to the next step THROUGH DEVICE MEMORY (the embedding kernel of step t+1 reads the token the argmax kernel of
 // step t wrote), so n_steps tokens are produced without a single host synchronisation.  Same kernels and the same per-row
 // arithmetic as the training forward pass: the tokens equal the full re-run's (tests/test_model_gpu.py).
+#include <type_traits>
+
 #include "omr_common.h"
 #include "omr_hip.h"
 
 namespace {
 
 struct Ws {          // activation scratch of one step, carved out of the caller's workspace
-    char* x; char* q; char* o; char* proj; char* h; char* logits; float* logits32; float* lse; float* mean; float* rstd;
+    char* x; char* x2; char* q; char* o; char* proj; char* h; char* logits; float* logits32; float* lse; float* mean; float* rstd;
     float* split; long split_floats;
     unsigned char* a8; float* sa8;          // fp8 mode: the quantised input rows of the current GEMM and their scales
 };
@@ -24,7 +26,7 @@ size_t carve(const omr_decode_desc& d, char* base, Ws* w) {
     const size_t es = d.dtype == OMR_BF16 ? 2 : 4, B = (size_t)d.B;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
-    char* x = take(B * d.d * es); char* q = take(B * d.d * es); char* o = take(B * d.d * es); char* proj = take(B * d.d * es);
+    char* x = take(B * d.d * es); char* x2 = take(B * d.d * es); char* q = take(B * d.d * es); char* o = take(B * d.d * es); char* proj = take(B * d.d * es);
     char* h = take(B * (size_t)d.ff * es); char* logits = take(B * (size_t)d.ldv * es);
     float* l32 = (float*)take(B * (size_t)d.ldv * 4); float* lse = (float*)take(B * (size_t)d.nhead * 4);
     float* mean = (float*)take(B * 4); float* rstd = (float*)take(B * 4);
@@ -34,13 +36,171 @@ size_t carve(const omr_decode_desc& d, char* base, Ws* w) {
     const size_t kmax = (size_t)(d.d > d.ff ? d.d : d.ff);
     unsigned char* a8 = (unsigned char*)take(d.fp8 ? B * ((kmax + 15) / 16 * 16) : 0);
     float* sa8 = (float*)take(d.fp8 ? B * 4 : 0);
-    if (w) *w = Ws{x, q, o, proj, h, logits, l32, lse, mean, rstd, split, sf, a8, sa8};
+    if (w) *w = Ws{x, x2, q, o, proj, h, logits, l32, lse, mean, rstd, split, sf, a8, sa8};
     return off;
 }
 
 #define TRY(call) do { int rc__ = (call); if (rc__ != OMR_OK) return rc__; } while (0)
 
+// ------------------------------------------------------------------------------------------------
+// Row linear of a decode position (omr_decode_linear).  A position is a chain of ~50 dependent launches of almost no work, so
+// what counts is how FEW launches there are and how short each one's dependent latency is -- not MFMA throughput (M = the
+// batch rows of one position).  Workgroup = 16 output columns x 16 k-lanes; the weight chunks of a thread are requested
+// first, the input rows are built while they fly (LayerNorm of the previous sub-layer / embedding / merge of the key-split
+// attention partials: the element-wise kernels that used to sit between the GEMMs), then a fixed-order fp32 dot product per
+// (row, column): chunks in ascending k, the 16 k-lanes combined by a butterfly.  blockIdx.y picks RM rows; nothing in a row's
+// arithmetic depends on M or on the other rows.
+constexpr int RM = 8, NOUT = 16, KL = 16, WCH = 8;      // rows per workgroup, columns per workgroup, k-lanes, prefetched weight chunks per thread
+constexpr int MAXSPLIT = 32;                            // key splits the merge prologue takes (256 keys each: S <= 8192)
+
+template <typename T>
+__global__ __launch_bounds__(256) void decode_linear_kernel(omr_decode_linear_args a) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float xs[];          // [RM][K]: the rows as the GEMM sees them (values rounded to T)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = tid / KL, kl = tid % KL;
+    const int n = blockIdx.x * NOUT + nl, K = a.K, nch = K / VEC;
+    const T* wrow = (const T*)a.w + (long)(n < a.N ? n : 0) * K;
+    F wv[WCH];
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+        const int c = kl + i * KL;
+        wv[i] = frag_zero<T>();
+        if (c < nch && n < a.N) wv[i] = *reinterpret_cast<const F*>(wrow + c * VEC);
+    }
+    const int per = K / 64;                                              // prologues 1-3: a wave builds a row, lane = `per` consecutive columns
+    {
+        const int r0 = blockIdx.y * RM, rm = min(RM, a.M - r0);
+        for (int r = wave; r < rm; r += 4) {
+            const long m = r0 + r;
+            float* xr = xs + r * K;
+            if (a.pro == 0) {
+                const T* src = (const T*)a.x + m * a.ldx;
+                for (int k = lane; k < K; k += 64) xr[k] = to_f32(src[k]);
+            } else if (a.pro == 1) {        // add + LayerNorm, same lane layout and summation order as add_ln_fwd_kernel (norm.hip)
+                const T* y = (const T*)a.x + m * a.ldx + lane * per;
+                const T* rs_ = (const T*)a.res + m * a.ldres + lane * per;
+                auto run = [&](auto per_c) {
+                    constexpr int PER = decltype(per_c)::value;
+                    float v[PER], mu, rstd;
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) v[i] = to_f32(y[i]) + to_f32(rs_[i]);
+                    ln_row<PER>(v, a.gamma, a.beta, lane, a.eps, mu, rstd);
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) {
+                        const T o = from_f32<T>(v[i]);
+                        xr[lane * PER + i] = to_f32(o);
+                        if (blockIdx.x == 0) ((T*)a.xn_out)[m * K + lane * PER + i] = o;
+                    }
+                };
+                if (per == 2) run(std::integral_constant<int, 2>());
+                else if (per == 4) run(std::integral_constant<int, 4>());
+                else run(std::integral_constant<int, 8>());
+            } else if (a.pro == 2) {        // embedding + positional row (embed_pe_kernel, elementwise.hip)
+                const long t = a.tokens[m];
+                const bool ok = t >= 0 && t < a.vocab;
+                for (int i = 0; i < per; ++i) {
+                    const int k = lane * per + i;
+                    const T o = from_f32<T>((ok ? to_f32(((const T*)a.emb)[t * K + k]) : 0.f) + a.pe_row[k]);
+                    xr[k] = to_f32(o);
+                    if (blockIdx.x == 0) ((T*)a.xn_out)[m * K + k] = o;
+                }
+            } else {                        // merge of the key-split partial softmaxes (attn_split_merge_kernel, attention.hip): same
+                                            // arithmetic in the same order; all loads of a pass are issued before the first use
+                for (int i = 0; i < per; ++i) {
+                    const int k = lane * per + i, h = k / a.hd, dch = k - h * a.hd, stride = a.hd + 2;
+                    const float* P = a.part + ((m * a.H + h) * a.nsplit) * stride;
+                    float mj[MAXSPLIT], lj[MAXSPLIT], oj[MAXSPLIT];
+#pragma unroll
+                    for (int j = 0; j < MAXSPLIT; ++j) {
+                        const bool on = j < a.nsplit;
+                        mj[j] = on ? P[j * stride + a.hd] : -INFINITY;
+                        lj[j] = on ? P[j * stride + a.hd + 1] : 0.f;
+                        oj[j] = on ? P[j * stride + dch] : 0.f;
+                    }
+                    float mm = -INFINITY;
+#pragma unroll
+                    for (int j = 0; j < MAXSPLIT; ++j) mm = fmaxf(mm, mj[j]);
+                    float l_tot = 0.f, o = 0.f;
+#pragma unroll
+                    for (int j = 0; j < MAXSPLIT; ++j)
+                        if (j < a.nsplit) {
+                            const float wj = mj[j] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mj[j] - mm);
+                            l_tot += lj[j] * wj;
+                            o += oj[j] * wj;
+                        }
+                    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+                    xr[k] = to_f32(from_f32<T>(o * inv));
+                }
+            }
+        }
+        __syncthreads();
+        float acc[RM];
+#pragma unroll
+        for (int r = 0; r < RM; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = kl + i * KL;
+            if (c < nch) {
+#pragma unroll
+                for (int r = 0; r < RM; ++r)
+                    if (r < rm)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[r] = fmaf(to_f32(wv[i][e]), xs[r * K + c * VEC + e], acc[r]);
+            }
+        }
+        for (int c = kl + WCH * KL; c < nch; c += KL) {                  // K beyond the prefetched chunks (ff_dim > WCH * KL * VEC)
+            const F wx = n < a.N ? *reinterpret_cast<const F*>(wrow + c * VEC) : frag_zero<T>();
+#pragma unroll
+            for (int r = 0; r < RM; ++r)
+                if (r < rm)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[r] = fmaf(to_f32(wx[e]), xs[r * K + c * VEC + e], acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+#pragma unroll
+            for (int o = KL / 2; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o, 64);
+        if (kl == 0 && n < a.N) {
+            const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < RM; ++r) {
+                if (r >= rm) break;
+                float v = acc[r] + bv;
+                if (a.relu) v = fmaxf(v, 0.f);
+                const T o = from_f32<T>(v);
+                const long m = r0 + r;
+                if (n < a.n0) ((T*)a.out0)[m * a.ld0 + n] = o;
+                else ((T*)a.out1)[m * a.ld1 + (n - a.n0)] = o;
+                if (a.out32) a.out32[m * a.ld32 + n] = to_f32(o);
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int omr_decode_linear(const omr_decode_linear_args* ap, void* stream) {
+    if (!ap) return OMR_ERR_ARG;
+    const omr_decode_linear_args& a = *ap;
+    const int vec = a.dtype == OMR_BF16 ? 8 : 4;
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % vec || a.K > 2048 || !a.w || !a.out0 || a.n0 < 0) return OMR_ERR_ARG;
+    if (((uintptr_t)a.w & 15) || (a.n0 < a.N && !a.out1)) return OMR_ERR_ARG;
+    if (a.pro < 0 || a.pro > 3) return OMR_ERR_ARG;
+    if (a.pro && (a.K % 64 || a.K / 64 > 16)) return OMR_ERR_ARG;
+    if (a.pro == 1 && a.K != 128 && a.K != 256 && a.K != 512) return OMR_ERR_UNSUPPORTED;      // the widths omr_add_layernorm_fwd takes
+    if ((a.pro == 0 || a.pro == 1) && !a.x) return OMR_ERR_ARG;
+    if (a.pro == 1 && (!a.res || !a.gamma || !a.beta || !a.xn_out)) return OMR_ERR_ARG;
+    if (a.pro == 2 && (!a.tokens || !a.emb || !a.pe_row || !a.xn_out)) return OMR_ERR_ARG;
+    if (a.pro == 3 && (!a.part || a.nsplit < 1 || a.nsplit > MAXSPLIT || a.H < 1 || a.hd < 1 || a.H * a.hd != a.K)) return OMR_ERR_ARG;
+    const dim3 grid((unsigned)cdiv(a.N, NOUT), (unsigned)cdiv(a.M, RM)), block(256);
+    const size_t shm = (size_t)RM * a.K * sizeof(float);
+    if (a.dtype == OMR_BF16) hipLaunchKernelGGL((decode_linear_kernel<bf16>), grid, block, shm, (hipStream_t)stream, a);
+    else if (a.dtype == OMR_F32) hipLaunchKernelGGL((decode_linear_kernel<float>), grid, block, shm, (hipStream_t)stream, a);
+    else return OMR_ERR_UNSUPPORTED;
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
 
 extern "C" long omr_decode_workspace_bytes(const omr_decode_desc* d) {
     if (!d || d->B <= 0 || d->d <= 0 || d->ff <= 0 || d->ldv < d->V) return OMR_ERR_ARG;
@@ -73,6 +233,69 @@ extern "C" int omr_decode_steps(const omr_decode_desc* dp, long* tokens, int t0,
         if (rc != OMR_OK) return rc;
         return omr_gemm_fp8(dt, B, N, K, w.a8, (K + 15) / 16 * 16, w.sa8, W8[mat] + (size_t)row0 * K, K, S8[mat] + row0, c, ldc, bias, relu, stream);
     };
+    // ---- bf16 / fp32: 8 launches per layer.  Every element-wise step between two linears (embedding + positional row, the
+    // three add + LayerNorm, the merge of the key-split attention) is folded into the loading of the NEXT linear's input rows
+    // (omr_decode_linear prologues); the residual stream alternates between two buffers because the workgroup that stores a
+    // freshly normalised row runs beside workgroups still reading the previous one.
+    if (!d.fp8 && (dm == 128 || dm == 256 || dm == 512) && d.ff <= 2048 && d.ff % 8 == 0 && d.S <= 256 * MAXSPLIT && d.max_len <= 256 * MAXSPLIT) {
+        const long* tok_in = tokens;
+        for (int s = 0; s < n_steps; ++s) {
+            const int t = t0 + s;
+            const int lo = (d.window > 0 && t - d.window > 0) ? t - d.window : 0;  // banded causal mask = a key range (decoder.py:213-214)
+            char* xa = w.x; char* xb = w.x2;                                        // xa: residual stream entering the sub-layer
+            auto lin = [&](int pro, const void* x, const void* res, const float* g, const float* bt, void* xn_out, const float* part, int nsplit,
+                           const void* wmat, const float* bias, int N, int K, int relu, void* out0, long ld0, int n0, void* out1, long ld1,
+                           float* out32) -> int {
+                omr_decode_linear_args a = {};
+                a.dtype = dt; a.pro = pro; a.M = B; a.N = N; a.K = K; a.relu = relu; a.n0 = n0; a.nsplit = nsplit; a.H = d.nhead; a.hd = hd; a.vocab = d.V;
+                a.eps = 1e-5f; a.x = x; a.ldx = K; a.res = res; a.ldres = K; a.gamma = g; a.beta = bt; a.xn_out = xn_out;
+                a.tokens = tok_in; a.emb = d.emb; a.pe_row = d.pe + (size_t)t * dm; a.part = part;
+                a.w = wmat; a.bias = bias; a.out0 = out0; a.ld0 = ld0; a.out1 = out1; a.ld1 = ld1; a.out32 = out32; a.ld32 = d.ldv;
+                return omr_decode_linear(&a, stream);
+            };
+            const float *pg = nullptr, *pb = nullptr;                               // norm3 of the previous layer, still to be applied
+            for (int l = 0; l < d.L; ++l) {
+                const void* const* Wl = d.layer_w + (size_t)l * OMR_DECODE_LAYER_PTRS;
+                char* cache_l = (char*)d.self_kv + ((size_t)l * B * d.max_len) * 2 * dm * es;
+                char* kv_row = cache_l + (size_t)t * 2 * dm * es;
+                // q | k|v projection of the position: q -> w.q, k|v straight into row t of the cache.  Its input is the
+                // embedding (layer 0) or norm3(x + ffn) of the previous layer; either way the rows land in xb
+                if (l == 0) TRY(lin(2, nullptr, nullptr, nullptr, nullptr, xb, nullptr, 0, Wl[0], (const float*)Wl[1], 3 * dm, dm, 0, w.q, dm, dm, kv_row, (long)d.max_len * 2 * dm, nullptr));
+                else TRY(lin(1, w.proj, xa, pg, pb, xb, nullptr, 0, Wl[0], (const float*)Wl[1], 3 * dm, dm, 0, w.q, dm, dm, kv_row, (long)d.max_len * 2 * dm, nullptr));
+                { char* tsw = xa; xa = xb; xb = tsw; }
+                const char* k0 = cache_l + (size_t)lo * 2 * dm * es;
+                int ns = 1;
+                TRY(omr_attn_fwd_split_partials(dt, w.q, k0, k0 + (size_t)dm * es, w.o, w.lse, dm, 2 * dm, 2 * dm, dm, dm, (long)d.max_len * 2 * dm,
+                                                (long)d.max_len * 2 * dm, dm, B, d.nhead, 1, t + 1 - lo, hd, w.split, w.split_floats, &ns, stream));
+                TRY(lin(ns > 1 ? 3 : 0, w.o, nullptr, nullptr, nullptr, nullptr, w.split, ns, Wl[2], (const float*)Wl[3], dm, dm, 0, w.proj, dm, dm, nullptr, 0, nullptr));
+                // cross-attention query from norm1(x + self-attention)
+                TRY(lin(1, w.proj, xa, (const float*)Wl[4], (const float*)Wl[5], xb, nullptr, 0, Wl[6], (const float*)Wl[7], dm, dm, 0, w.q, dm, dm, nullptr, 0, nullptr));
+                { char* tsw = xa; xa = xb; xb = tsw; }
+                const char* ck = (const char*)d.cross_kv + (size_t)l * 2 * dm * es;
+                TRY(omr_attn_fwd_split_partials(dt, w.q, ck, ck + (size_t)dm * es, w.o, w.lse, dm, d.cross_ld, d.cross_ld, dm, dm, d.cross_bs, d.cross_bs, dm,
+                                                B, d.nhead, 1, d.S, hd, w.split, w.split_floats, &ns, stream));
+                TRY(lin(ns > 1 ? 3 : 0, w.o, nullptr, nullptr, nullptr, nullptr, w.split, ns, Wl[8], (const float*)Wl[9], dm, dm, 0, w.proj, dm, dm, nullptr, 0, nullptr));
+                // feed-forward from norm2(x + cross-attention)
+                TRY(lin(1, w.proj, xa, (const float*)Wl[10], (const float*)Wl[11], xb, nullptr, 0, Wl[12], (const float*)Wl[13], d.ff, dm, 1, w.h, d.ff, d.ff, nullptr, 0, nullptr));
+                { char* tsw = xa; xa = xb; xb = tsw; }
+                TRY(lin(0, w.h, nullptr, nullptr, nullptr, nullptr, nullptr, 0, Wl[14], (const float*)Wl[15], dm, d.ff, 0, w.proj, dm, dm, nullptr, 0, nullptr));
+                pg = (const float*)Wl[16]; pb = (const float*)Wl[17];
+            }
+            // vocabulary head (Conv1d k=1, decoder.py:145-146) on norm3 of the last layer: logits rounded to the compute dtype like
+            // the training forward, kept as fp32 rows
+            TRY(lin(1, w.proj, xa, pg, pb, xb, nullptr, 0, d.head_w, d.head_b, d.V, dm, 0, w.logits, d.ldv, d.V, nullptr, 0, w.logits32));
+            if (out_tokens) {   // greedy pick (model.py:187,253); the next position reads the token from where the argmax wrote it
+                TRY(omr_argmax(w.logits32, B, d.V, d.ldv, out_tokens + (size_t)s * B, out_top1 ? out_top1 + (size_t)s * B : nullptr, stream));
+                tok_in = out_tokens + (size_t)s * B;
+            }
+        }
+        if (out_tokens && hipMemcpyAsync(tokens, out_tokens + (size_t)(n_steps - 1) * B, (size_t)B * sizeof(long), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+            return OMR_ERR_LAUNCH;
+        if (last_logits && hipMemcpyAsync(last_logits, w.logits32, (size_t)B * d.ldv * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+            return OMR_ERR_LAUNCH;
+        return OMR_OK;
+    }
+    // ---- fp8 weights (and model widths the row kernel does not take): one GEMM / element-wise kernel per step of the layer
     for (int s = 0; s < n_steps; ++s) {
         const int t = t0 + s;
         // embedding(tgt) + pe[t]  (decoder.py:124; T_len = 1 so every row of the batch takes the table row given)

@@ -164,9 +164,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
     const long row = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
     const VT xv = *reinterpret_cast<const VT*>(x + row * d + lane * PER);
-    const VF gm = *reinterpret_cast<const VF*>(gamma + lane * PER), bt = *reinterpret_cast<const VF*>(beta + lane * PER);
     float v[PER];
-    float s = 0.f;
 #pragma unroll
     for (int i = 0; i < PER; ++i) v[i] = to_f32(xv[i]);
     if (drop_thresh) {
@@ -180,16 +178,11 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
 #pragma unroll
         for (int i = 0; i < PER; ++i) v[i] += to_f32(rv[i]);
     }
-#pragma unroll
-    for (int i = 0; i < PER; ++i) s += v[i];
-    const float mu = wave_sum(s) * (1.f / d);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) { const float t = v[i] - mu; q += t * t; }
-    const float rs = rsqrtf(wave_sum(q) * (1.f / d) + eps);
+    float mu, rs;
+    ln_row<PER>(v, gamma, beta, lane, eps, mu, rs);
     VT o;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) o[i] = from_f32<T>((v[i] - mu) * rs * gm[i] + bt[i]);
+    for (int i = 0; i < PER; ++i) o[i] = from_f32<T>(v[i]);
     *reinterpret_cast<VT*>(out + row * d + lane * PER) = o;
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }

@@ -75,6 +75,26 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// LayerNorm of one row held by a wave, lane = PER consecutive columns: v <- (v - mean) * rstd * gamma + beta.  One definition
+// for add_ln_fwd_kernel (norm.hip) and the decode row kernel's prologue (decode.hip): the KV-cached step has to build the rows
+// the training forward builds, to the bit.
+template <int PER>
+__device__ __forceinline__ void ln_row(float (&v)[PER], const float* __restrict__ gamma, const float* __restrict__ beta, int lane, float eps, float& mu,
+                                       float& rs) {
+    constexpr int d = PER * 64;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s += v[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    mu = s * (1.f / d);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const float t = v[i] - mu; q += t * t; }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    rs = rsqrtf(q * (1.f / d) + eps);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) v[i] = (v[i] - mu) * rs * gamma[lane * PER + i] + beta[lane * PER + i];
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

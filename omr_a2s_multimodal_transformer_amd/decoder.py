@@ -26,6 +26,15 @@ def sinusoid_1d(max_len: int, emb_dim: int) -> torch.Tensor:
     return pe
 
 
+def _to_dev(t: torch.Tensor, device) -> torch.Tensor:
+    """Host -> device without blocking the host (pinned staging + non-blocking copy); device tensors pass through."""
+    if t.device == device:
+        return t
+    if not t.is_cuda and not t.is_pinned() and torch.cuda.is_available():
+        t = t.pin_memory()
+    return t.to(device, non_blocking=True)
+
+
 def _dropout(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
     if not training or p <= 0.0:
         return x
@@ -276,12 +285,18 @@ class Decoder(nn.Module):
             memory = K.cast(memory.contiguous(), dt)
         memory = memory.contiguous()
         B, T = tgt.shape
+        # Host copies of the token ids / integer lengths (the Trainer keeps integer tensors on the host) tell, without a device
+        # round trip, when a mask is all zeros: adding 0.0 to every score is the identity, so such a mask is not built and the
+        # attention kernels take their bias-free path.  Device-resident inputs keep the general path.
+        mem_full = memory_len is not None and not memory_len.is_cuda and memory_len.dtype != torch.bool and bool((memory_len >= memory.shape[1]).all())
+        tgt_no_pad = not tgt.is_cuda and not bool((tgt == 0).any())
+        tgt = _to_dev(tgt, memory.device)
         x = Fn.EmbedPEFn.apply(tgt.contiguous(), emb_w, self.pos_1d.pe[0], self.padding_idx, dt)
         x = _dropout(x, self.pos_1d.dropout_p, self.training)
-        mem_mask = self.get_memory_key_padding_mask(memory, memory_len)
+        mem_mask = None if mem_full else self.get_memory_key_padding_mask(memory, None if memory_len is None else _to_dev(memory_len, memory.device))
         mem_bias = self._as_key_bias(mem_mask)
         # tgt_key_padding_mask = (tgt == 0).float() is ADDED (+1.0); dropped when there is no memory mask (decoder.py:131-132)
-        self_bias = None if mem_mask is None else (tgt == 0).to(torch.float32).contiguous()
+        self_bias = None if (memory_len is None or tgt_no_pad) else (tgt == 0).to(torch.float32).contiguous()
         window = self.attn_window if self.attn_window > 0 else -1
         layers = self.transformer_decoder.layers
         pack = self._cross_kv_pack(dt)

@@ -77,6 +77,63 @@ class _DwProblem(ctypes.Structure):
                 ("row_group_stride", ctypes.c_int), ("row_group_base", ctypes.c_int)]
 
 
+class _DecodeLinearArgs(ctypes.Structure):
+    """omr_decode_linear_args of include/omr_hip.h."""
+    _fields_ = [(n, ctypes.c_int) for n in ("dtype", "pro", "M", "N", "K", "relu", "n0", "nsplit", "H", "hd", "vocab", "pad_")] + \
+               [("eps", ctypes.c_float), ("pad2_", ctypes.c_float),
+                ("x", ctypes.c_void_p), ("ldx", ctypes.c_long), ("res", ctypes.c_void_p), ("ldres", ctypes.c_long),
+                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("xn_out", ctypes.c_void_p),
+                ("tokens", ctypes.c_void_p), ("emb", ctypes.c_void_p), ("pe_row", ctypes.c_void_p), ("part", ctypes.c_void_p),
+                ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("out0", ctypes.c_void_p), ("ld0", ctypes.c_long),
+                ("out1", ctypes.c_void_p), ("ld1", ctypes.c_long), ("out32", ctypes.c_void_p), ("ld32", ctypes.c_long)]
+
+
+def decode_linear(w: Tensor, bias: Optional[Tensor], *, x: Optional[Tensor] = None, res: Optional[Tensor] = None, ln=None, tokens: Optional[Tensor] = None,
+                  emb: Optional[Tensor] = None, pe_row: Optional[Tensor] = None, part: Optional[Tensor] = None, heads: int = 0, relu: bool = False,
+                  n0: Optional[int] = None, want32: bool = False):
+    """One linear of a decode position with the preceding element-wise step folded into its input rows (omr_decode_linear):
+    x alone -> plain rows; x + res + ln=(gamma, beta, eps) -> LayerNorm(x + res); tokens + emb + pe_row -> embedding row + pe;
+    part [M*heads, nsplit, hd+2] + heads -> merged key-split attention.  Returns (out0 [M, n0], out1 [M, N-n0] or None,
+    built rows [M, K] or None, fp32 copy or None)."""
+    require_cuda(w, bias, x, res, tokens, emb, pe_row, part)
+    N, K = w.shape
+    dt = w.dtype
+    a = _DecodeLinearArgs()
+    built = None
+    if part is not None:
+        pro, M = 3, part.shape[0] // heads
+        assert part.dtype == torch.float32 and part.is_contiguous() and part.shape[2] - 2 == K // heads
+        a.part, a.nsplit, a.H, a.hd = part.data_ptr(), part.shape[1], heads, K // heads
+    elif tokens is not None:
+        pro, M = 2, tokens.numel()
+        assert tokens.dtype == torch.int64 and emb.dtype == dt and emb.is_contiguous() and pe_row.dtype == torch.float32 and pe_row.numel() == K
+        built = torch.empty((M, K), dtype=dt, device=w.device)
+        a.tokens, a.emb, a.pe_row, a.vocab, a.xn_out = tokens.data_ptr(), emb.data_ptr(), pe_row.data_ptr(), emb.shape[0], built.data_ptr()
+    elif ln is not None:
+        pro, M = 1, x.shape[0]
+        gamma, beta, eps = ln
+        assert x.dtype == res.dtype == dt and x.stride(1) == res.stride(1) == 1 and gamma.dtype == beta.dtype == torch.float32
+        built = torch.empty((M, K), dtype=dt, device=w.device)
+        a.x, a.ldx, a.res, a.ldres, a.gamma, a.beta, a.eps, a.xn_out = x.data_ptr(), x.stride(0), res.data_ptr(), res.stride(0), gamma.data_ptr(), beta.data_ptr(), eps, built.data_ptr()
+    else:
+        pro, M = 0, x.shape[0]
+        assert x.dtype == dt and x.stride(1) == 1 and x.shape[1] == K
+        a.x, a.ldx = x.data_ptr(), x.stride(0)
+    n0 = N if n0 is None else n0
+    out0 = torch.empty((M, n0), dtype=dt, device=w.device)
+    out1 = torch.empty((M, N - n0), dtype=dt, device=w.device) if n0 < N else None
+    out32 = torch.empty((M, N), dtype=torch.float32, device=w.device) if want32 else None
+    assert w.is_contiguous() and (bias is None or (bias.dtype == torch.float32 and bias.numel() == N))
+    a.dtype, a.pro, a.M, a.N, a.K, a.relu, a.n0 = dtype_code(dt), pro, M, N, K, int(relu), n0
+    a.w, a.bias, a.out0, a.ld0 = w.data_ptr(), (bias.data_ptr() if bias is not None else None), out0.data_ptr(), n0
+    if out1 is not None:
+        a.out1, a.ld1 = out1.data_ptr(), N - n0
+    if out32 is not None:
+        a.out32, a.ld32 = out32.data_ptr(), N
+    lib().call("omr_decode_linear", ctypes.byref(a), cur_stream())
+    return out0, out1, built, out32
+
+
 def linear_wgrad_grouped(problems) -> None:
     """Weight / bias gradients of several linear layers in ONE launch (omr_linear_wgrad_grouped).  problems: sequence of
     (dy [rows, n_out], x [rows, n_in], dw fp32 [n_out(+), n_in] accumulated in place, db fp32 or None, group) with
@@ -450,6 +507,26 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, nhead: int, *, causal: bool = Fals
     lib().call("omr_attn_fwd_ws", dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, nhead, T, S, hd,
                int(causal), int(window), ptr(key_bias), ptr(blk_lq), ptr(blk_lkv), float(dropout_p), int(seed) & (2**64 - 1), ptr(ws), nws, cur_stream())
     return o, lse
+
+
+def attn_fwd_split_partials(q: Tensor, k: Tensor, v: Tensor, nhead: int):
+    """Decode attention (q [B,1,d]) stopped before its merge pass: -> (partials [B*H, nsplit, hd+2], nsplit); with nsplit == 1
+    the first return value is the finished output [B,1,d] instead (omr_attn_fwd_split_partials)."""
+    require_cuda(q, k, v)
+    B, T, d = q.shape
+    S, hd = k.shape[1], d // nhead
+    assert T == 1
+    o = torch.empty((B, T, d), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, nhead, T), dtype=torch.float32, device=q.device)
+    n = lib().query("omr_attn_split_workspace_floats", B, nhead, T, S, hd)
+    ws = torch.empty(max(n, 1), dtype=torch.float32, device=q.device)
+    ns = ctypes.c_int(0)
+    (ldq, bsq), (ldk, bsk), (ldv, bsv), (ldo, bso) = _bts(q), _bts(k), _bts(v), _bts(o)
+    lib().call("omr_attn_fwd_split_partials", dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, nhead, T, S,
+               hd, ptr(ws), n, ctypes.byref(ns), cur_stream())
+    if ns.value <= 1:
+        return o, 1
+    return ws[:B * nhead * ns.value * (hd + 2)].view(B * nhead, ns.value, hd + 2), ns.value
 
 
 def _attn_ws(B: int, H: int, T: int, S: int, hd: int, causal: bool, backward: bool, device):

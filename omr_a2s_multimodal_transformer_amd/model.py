@@ -307,7 +307,7 @@ class Transformer(_Base):
 
     def forward(self, x: torch.Tensor, xl: torch.Tensor, y_in: torch.Tensor) -> torch.Tensor:
         mem = self.encode(x)
-        return self.decoder(tgt=_h2d(y_in, mem.device), memory=mem, memory_len=None if xl is None else _h2d(xl, mem.device))
+        return self.decoder(tgt=y_in, memory=mem, memory_len=xl)     # host-resident ids / lengths go as they are: the decoder reads them before the copy
 
     def apply_teacher_forcing(self, y: torch.Tensor) -> torch.Tensor:
         """model.py:152-160: each non-pad token is replaced w.p. teacher_forcing_prob by randint(0, V-1) drawn
@@ -426,7 +426,7 @@ class MultimodalTransformer(_Base):
 
     def forward(self, xi, xli, xa, xla, y_in, apply_teacher_forcing_modality: bool = False) -> torch.Tensor:
         x, xl = self.encoder_forward(xi=xi, xa=xa, xli=xli, xla=xla, apply_teacher_forcing_modality=apply_teacher_forcing_modality)
-        return self.decoder(tgt=_h2d(y_in, x.device), memory=x, memory_len=None if xl is None else _h2d(xl, x.device))
+        return self.decoder(tgt=y_in, memory=x, memory_len=xl)
 
     def apply_teacher_forcing(self, y: torch.Tensor) -> torch.Tensor:
         """model.py:545-559 (vectorised, torch RNG)."""

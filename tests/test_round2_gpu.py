@@ -292,3 +292,51 @@ def test_native_decode_runs_of_tokens_equal_single_steps(dtype, win, B):
     assert torch.equal(st_run.self_kv[:, :, :13], st_one.self_kv[:, :, :13])
     with pytest.raises(RuntimeError):
         m.decoder.decode_tokens(tok, st_run, 8)                                      # 13 + 8 > max_seq_len 20: positional table exhausted
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 5, 19])
+def test_decode_row_linear_prologues_equal_the_separate_kernels(dtype, M):
+    """omr_decode_linear: each prologue builds exactly the rows the stand-alone kernel would have written (add + LayerNorm,
+    embedding + positional row, key-split merge), the linear itself matches the MFMA GEMM on those rows to fp32 round-off, and
+    a row's result does not depend on how many rows share the launch."""
+    from omr_a2s_multimodal_transformer_amd import kernels as K
+    g = torch.Generator().manual_seed(31 + M)
+    d, ff, V, H = 128, 320, 77, 4
+    dev = DEV
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dev).to(dtype)
+    w1, b1 = r(ff, d), torch.randn(ff, generator=g).to(dev)
+    w2, b2 = r(3 * d, ff), torch.randn(3 * d, generator=g).to(dev)
+    y, res = r(M, d), r(M, d)
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=g)).to(dev), (0.1 * torch.randn(d, generator=g)).to(dev)
+    tol = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    # 1: LayerNorm(y + res) prologue, ReLU epilogue
+    xn_ref, _, _ = K.add_layernorm_fwd(y, res, gamma, beta, 1e-5)
+    h, _, built, _ = K.decode_linear(w1, b1, x=y, res=res, ln=(gamma, beta, 1e-5), relu=True)
+    assert torch.equal(built, xn_ref)
+    torch.testing.assert_close(h.float(), torch.relu(xn_ref.float() @ w1.float().t() + b1), **tol)
+    # 0: plain rows, two output segments, fp32 copy of the rounded values
+    o0, o1, _, o32 = K.decode_linear(w2, b2, x=h, n0=d, want32=True)
+    ref = h.float() @ w2.float().t() + b2
+    torch.testing.assert_close(torch.cat([o0, o1], 1).float(), ref, **tol)
+    assert torch.equal(o32, torch.cat([o0, o1], 1).float())
+    # row independence: the same rows alone
+    for i in (0, M - 1):
+        a0, a1, _, _ = K.decode_linear(w2, b2, x=h[i:i + 1].contiguous(), n0=d)
+        assert torch.equal(a0[0], o0[i]) and torch.equal(a1[0], o1[i])
+    # 2: embedding + positional row
+    emb, pe = r(V, d), torch.randn(d, generator=g).to(dev)
+    tok = torch.randint(0, V, (M,), generator=g).to(dev)
+    q, _, built, _ = K.decode_linear(w1, b1, tokens=tok, emb=emb, pe_row=pe)
+    ref_rows = (emb[tok].float() + pe).to(dtype)
+    assert torch.equal(built, ref_rows)
+    torch.testing.assert_close(q.float(), ref_rows.float() @ w1.float().t() + b1, **tol)
+    # 3: merge of key-split partials = the attention's own merge kernel
+    S, hd = 1100, d // H
+    qq, kv = r(M, 1, d), r(M, S, 2 * d)
+    o_ref, _ = K.attn_fwd(qq, kv[..., :d], kv[..., d:], H)
+    part, ns = K.attn_fwd_split_partials(qq, kv[..., :d], kv[..., d:], H)
+    assert ns > 1
+    wo, bo = r(d, d), torch.randn(d, generator=g).to(dev)
+    o, _, _, _ = K.decode_linear(wo, bo, part=part, heads=H)
+    torch.testing.assert_close(o.float(), o_ref.view(M, d).float() @ wo.float().t() + bo, **tol)
