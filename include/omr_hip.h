@@ -260,6 +260,9 @@ long omr_decode_workspace_bytes(const omr_decode_desc* desc);
  * [0, n0) go to out0 (ld0), the rest to out1 (ld1) -- a q | k|v projection writes its k|v part straight into the cache row;
  * out32 (nullable, ld32): fp32 copy of the value rounded to `dtype` (the vocabulary head's logits).  Each (row, column) is
  * a fixed-order fp32 sum that does not depend on M: a batched step reproduces the single-row step to the bit.
+ * amax_idx (nullable): also return, per row, the first index of the largest rounded output and its value (the greedy pick of
+ * model.py:187,253): every workgroup leaves its 16-column candidate in amax_part (>= 2 * M * ceil(N/16) floats of scratch) and
+ * a second, one-wave-per-row launch reduces them -- cheaper than a pass over the N logits.
  * Requires K % 64 == 0 for prologues 1-3, K <= 2048, 16-byte aligned weight rows. */
 typedef struct omr_decode_linear_args {
     int dtype, pro, M, N, K, relu, n0, nsplit, H, hd, vocab, pad_;
@@ -267,6 +270,7 @@ typedef struct omr_decode_linear_args {
     const void* x; long ldx; const void* res; long ldres; const float* gamma; const float* beta; void* xn_out;
     const long* tokens; const void* emb; const float* pe_row; const float* part;
     const void* w; const float* bias; void* out0; long ld0; void* out1; long ld1; float* out32; long ld32;
+    long* amax_idx; float* amax_val; float* amax_part;
 } omr_decode_linear_args;
 int omr_decode_linear(const omr_decode_linear_args* args, void* stream);
 int omr_decode_steps(const omr_decode_desc* desc, long* tokens, int t0, int n_steps, long* out_tokens, float* out_top1, float* last_logits,

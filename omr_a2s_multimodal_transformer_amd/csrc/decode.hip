@@ -16,7 +16,7 @@ namespace {
 
 struct Ws {          // activation scratch of one step, carved out of the caller's workspace
     char* x; char* x2; char* q; char* o; char* proj; char* h; char* logits; float* logits32; float* lse; float* mean; float* rstd;
-    float* split; long split_floats;
+    float* split; long split_floats; float* apart;
     unsigned char* a8; float* sa8;          // fp8 mode: the quantised input rows of the current GEMM and their scales
 };
 
@@ -33,10 +33,11 @@ size_t carve(const omr_decode_desc& d, char* base, Ws* w) {
     const int smax = d.S > d.max_len ? d.S : d.max_len;                // key-split partials of the longer of the two attentions
     const long sf = omr_attn_split_workspace_floats(d.B, d.nhead, 1, smax, d.d / d.nhead);
     float* split = (float*)take((size_t)sf * 4);
+    float* apart = (float*)take(2 * B * (size_t)((d.V + 15) / 16) * 4);      // greedy pick: the head kernel's per-workgroup candidates
     const size_t kmax = (size_t)(d.d > d.ff ? d.d : d.ff);
     unsigned char* a8 = (unsigned char*)take(d.fp8 ? B * ((kmax + 15) / 16 * 16) : 0);
     float* sa8 = (float*)take(d.fp8 ? B * 4 : 0);
-    if (w) *w = Ws{x, x2, q, o, proj, h, logits, l32, lse, mean, rstd, split, sf, a8, sa8};
+    if (w) *w = Ws{x, x2, q, o, proj, h, logits, l32, lse, mean, rstd, split, sf, apart, a8, sa8};
     return off;
 }
 
@@ -51,13 +52,15 @@ size_t carve(const omr_decode_desc& d, char* base, Ws* w) {
 // (row, column): chunks in ascending k, the 16 k-lanes combined by a butterfly.  blockIdx.y picks RM rows; nothing in a row's
 // arithmetic depends on M or on the other rows.
 constexpr int RM = 8, NOUT = 16, KL = 16, WCH = 8;      // rows per workgroup, columns per workgroup, k-lanes, prefetched weight chunks per thread
-constexpr int MAXSPLIT = 32;                            // key splits the merge prologue takes (256 keys each: S <= 8192)
+constexpr int MAXSPLIT = 32, MAXHS = 256;                // key splits the merge prologue takes (256 keys each: S <= 8192); heads x splits
 
 template <typename T>
 __global__ __launch_bounds__(256) void decode_linear_kernel(omr_decode_linear_args a) {
     typedef typename Frag<T>::type F;
     constexpr int VEC = Frag<T>::N;
     extern __shared__ __attribute__((aligned(16))) float xs[];          // [RM][K]: the rows as the GEMM sees them (values rounded to T)
+    __shared__ float mls[4 * 2 * MAXHS];                                 // prologue 3: per-wave (max | sum) strips
+    __shared__ float cand[RM][NOUT];                                     // greedy pick: the workgroup's rounded outputs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = tid / KL, kl = tid % KL;
     const int n = blockIdx.x * NOUT + nl, K = a.K, nch = K / VEC;
     const T* wrow = (const T*)a.w + (long)(n < a.N ? n : 0) * K;
@@ -105,33 +108,38 @@ __global__ __launch_bounds__(256) void decode_linear_kernel(omr_decode_linear_ar
                     xr[k] = to_f32(o);
                     if (blockIdx.x == 0) ((T*)a.xn_out)[m * K + k] = o;
                 }
-            } else {                        // merge of the key-split partial softmaxes (attn_split_merge_kernel, attention.hip): same
-                                            // arithmetic in the same order; all loads of a pass are issued before the first use
-                for (int i = 0; i < per; ++i) {
-                    const int k = lane * per + i, h = k / a.hd, dch = k - h * a.hd, stride = a.hd + 2;
-                    const float* P = a.part + ((m * a.H + h) * a.nsplit) * stride;
-                    float mj[MAXSPLIT], lj[MAXSPLIT], oj[MAXSPLIT];
-#pragma unroll
-                    for (int j = 0; j < MAXSPLIT; ++j) {
-                        const bool on = j < a.nsplit;
-                        mj[j] = on ? P[j * stride + a.hd] : -INFINITY;
-                        lj[j] = on ? P[j * stride + a.hd + 1] : 0.f;
-                        oj[j] = on ? P[j * stride + dch] : 0.f;
-                    }
-                    float mm = -INFINITY;
-#pragma unroll
-                    for (int j = 0; j < MAXSPLIT; ++j) mm = fmaxf(mm, mj[j]);
-                    float l_tot = 0.f, o = 0.f;
-#pragma unroll
-                    for (int j = 0; j < MAXSPLIT; ++j)
-                        if (j < a.nsplit) {
-                            const float wj = mj[j] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mj[j] - mm);
-                            l_tot += lj[j] * wj;
-                            o += oj[j] * wj;
-                        }
-                    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-                    xr[k] = to_f32(from_f32<T>(o * inv));
+            } else {                        // merge of the key-split partial softmaxes: attn_split_merge_kernel's arithmetic in its
+                                            // order.  The (max, sum) pairs of the row's H * nsplit partials go through a per-wave LDS
+                                            // strip first (one global round trip for all of them); a lane's `per` columns lie in one head
+                const int hs = a.H * a.nsplit, stride = a.hd + 2;
+                float* ml = mls + wave * (2 * MAXHS);
+                for (int l = lane; l < hs; l += 64) {
+                    const float* P = a.part + (m * hs + l) * stride;
+                    ml[l] = P[a.hd];
+                    ml[MAXHS + l] = P[a.hd + 1];
                 }
+                // the LDS queue of a wave is in order: the reads below follow the writes above
+                const int h = (lane * per) / a.hd, dch = lane * per - h * a.hd;
+                const float* mh = ml + h * a.nsplit;
+                const float* P = a.part + ((m * a.H + h) * a.nsplit) * stride + dch;
+                float mm = -INFINITY;
+                for (int j = 0; j < a.nsplit; ++j) mm = fmaxf(mm, mh[j]);
+                float l_tot = 0.f, o[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[i] = 0.f;
+#pragma unroll 4
+                for (int j = 0; j < a.nsplit; ++j) {
+                    const float mj = mh[j];
+                    const float wj = mj == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mj - mm);
+                    l_tot += mh[MAXHS + j] * wj;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (i < per) o[i] += P[j * stride + i] * wj;
+                }
+                const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (i < per) xr[lane * per + i] = to_f32(from_f32<T>(o[i] * inv));
             }
         }
         __syncthreads();
@@ -173,9 +181,45 @@ __global__ __launch_bounds__(256) void decode_linear_kernel(omr_decode_linear_ar
                 if (n < a.n0) ((T*)a.out0)[m * a.ld0 + n] = o;
                 else ((T*)a.out1)[m * a.ld1 + (n - a.n0)] = o;
                 if (a.out32) a.out32[m * a.ld32 + n] = to_f32(o);
+                cand[r][nl] = to_f32(o);
+            }
+        }
+        // ---- greedy pick, first half: this workgroup's candidate per row (value, column); decode_pick_kernel reduces the
+        //      ceil(N/16) candidates of a row.  (Letting the last workgroup to finish do that -- counter + agent-scope fences --
+        //      was measured: 20 us slower per position than the second launch.)
+        if (a.amax_part) {
+            if (kl == 0 && n >= a.N)
+#pragma unroll
+                for (int r = 0; r < RM; ++r) cand[r][nl] = -INFINITY;
+            __syncthreads();
+            if (tid < rm) {
+                float best = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+                for (int c = 0; c < NOUT; ++c) {
+                    const float v = cand[tid][c];
+                    if (v > best) { best = v; bi = blockIdx.x * NOUT + c; }            // ascending columns: the first maximum stays
+                }
+                float* pp = a.amax_part + ((long)(r0 + tid) * gridDim.x + blockIdx.x) * 2;
+                pp[0] = best; pp[1] = __int_as_float(bi);
             }
         }
     }
+}
+
+// greedy pick, second half: one wave per row over the G (value, column) candidates; first index of the maximum (torch.argmax)
+__global__ __launch_bounds__(64) void decode_pick_kernel(const float* __restrict__ part, int G, long* __restrict__ idx_out, float* __restrict__ val_out) {
+    const int lane = threadIdx.x;
+    const float* pp = part + (long)blockIdx.x * G * 2;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int i = lane; i < G; i += 64) {
+        const float v = pp[2 * i]; const int ii = __float_as_int(pp[2 * i + 1]);
+        if (v > best || (v == best && ii < bi)) { best = v; bi = ii; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v = __shfl_xor(best, o, 64); const int ii = __shfl_xor(bi, o, 64);
+        if (v > best || (v == best && ii < bi)) { best = v; bi = ii; }
+    }
+    if (lane == 0) { idx_out[blockIdx.x] = bi; if (val_out) val_out[blockIdx.x] = best; }
 }
 
 }  // namespace
@@ -187,17 +231,19 @@ extern "C" int omr_decode_linear(const omr_decode_linear_args* ap, void* stream)
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % vec || a.K > 2048 || !a.w || !a.out0 || a.n0 < 0) return OMR_ERR_ARG;
     if (((uintptr_t)a.w & 15) || (a.n0 < a.N && !a.out1)) return OMR_ERR_ARG;
     if (a.pro < 0 || a.pro > 3) return OMR_ERR_ARG;
+    if (a.amax_idx && !a.amax_part) return OMR_ERR_ARG;
     if (a.pro && (a.K % 64 || a.K / 64 > 16)) return OMR_ERR_ARG;
     if (a.pro == 1 && a.K != 128 && a.K != 256 && a.K != 512) return OMR_ERR_UNSUPPORTED;      // the widths omr_add_layernorm_fwd takes
     if ((a.pro == 0 || a.pro == 1) && !a.x) return OMR_ERR_ARG;
     if (a.pro == 1 && (!a.res || !a.gamma || !a.beta || !a.xn_out)) return OMR_ERR_ARG;
     if (a.pro == 2 && (!a.tokens || !a.emb || !a.pe_row || !a.xn_out)) return OMR_ERR_ARG;
-    if (a.pro == 3 && (!a.part || a.nsplit < 1 || a.nsplit > MAXSPLIT || a.H < 1 || a.hd < 1 || a.H * a.hd != a.K)) return OMR_ERR_ARG;
+    if (a.pro == 3 && (!a.part || a.nsplit < 1 || a.nsplit > MAXSPLIT || a.H < 1 || a.hd < 1 || a.H * a.hd != a.K || a.H * a.nsplit > MAXHS || a.hd % (a.K / 64))) return OMR_ERR_ARG;
     const dim3 grid((unsigned)cdiv(a.N, NOUT), (unsigned)cdiv(a.M, RM)), block(256);
     const size_t shm = (size_t)RM * a.K * sizeof(float);
     if (a.dtype == OMR_BF16) hipLaunchKernelGGL((decode_linear_kernel<bf16>), grid, block, shm, (hipStream_t)stream, a);
     else if (a.dtype == OMR_F32) hipLaunchKernelGGL((decode_linear_kernel<float>), grid, block, shm, (hipStream_t)stream, a);
     else return OMR_ERR_UNSUPPORTED;
+    if (a.amax_idx) hipLaunchKernelGGL(decode_pick_kernel, dim3((unsigned)a.M), dim3(64), 0, (hipStream_t)stream, a.amax_part, (int)grid.x, a.amax_idx, a.amax_val);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }
@@ -245,8 +291,9 @@ extern "C" int omr_decode_steps(const omr_decode_desc* dp, long* tokens, int t0,
             char* xa = w.x; char* xb = w.x2;                                        // xa: residual stream entering the sub-layer
             auto lin = [&](int pro, const void* x, const void* res, const float* g, const float* bt, void* xn_out, const float* part, int nsplit,
                            const void* wmat, const float* bias, int N, int K, int relu, void* out0, long ld0, int n0, void* out1, long ld1,
-                           float* out32) -> int {
+                           float* out32, long* amax_idx = nullptr, float* amax_val = nullptr) -> int {
                 omr_decode_linear_args a = {};
+                a.amax_idx = amax_idx; a.amax_val = amax_val; a.amax_part = amax_idx ? w.apart : nullptr;
                 a.dtype = dt; a.pro = pro; a.M = B; a.N = N; a.K = K; a.relu = relu; a.n0 = n0; a.nsplit = nsplit; a.H = d.nhead; a.hd = hd; a.vocab = d.V;
                 a.eps = 1e-5f; a.x = x; a.ldx = K; a.res = res; a.ldres = K; a.gamma = g; a.beta = bt; a.xn_out = xn_out;
                 a.tokens = tok_in; a.emb = d.emb; a.pe_row = d.pe + (size_t)t * dm; a.part = part;
@@ -283,11 +330,11 @@ extern "C" int omr_decode_steps(const omr_decode_desc* dp, long* tokens, int t0,
             }
             // vocabulary head (Conv1d k=1, decoder.py:145-146) on norm3 of the last layer: logits rounded to the compute dtype like
             // the training forward, kept as fp32 rows
-            TRY(lin(1, w.proj, xa, pg, pb, xb, nullptr, 0, d.head_w, d.head_b, d.V, dm, 0, w.logits, d.ldv, d.V, nullptr, 0, w.logits32));
-            if (out_tokens) {   // greedy pick (model.py:187,253); the next position reads the token from where the argmax wrote it
-                TRY(omr_argmax(w.logits32, B, d.V, d.ldv, out_tokens + (size_t)s * B, out_top1 ? out_top1 + (size_t)s * B : nullptr, stream));
-                tok_in = out_tokens + (size_t)s * B;
-            }
+            // ... and the greedy pick (model.py:187,253): candidates from the head's workgroups, one small launch to reduce them; the
+            // next position reads the token from where it was written
+            TRY(lin(1, w.proj, xa, pg, pb, xb, nullptr, 0, d.head_w, d.head_b, d.V, dm, 0, w.logits, d.ldv, d.V, nullptr, 0, w.logits32,
+                    out_tokens ? out_tokens + (size_t)s * B : nullptr, (out_tokens && out_top1) ? out_top1 + (size_t)s * B : nullptr));
+            if (out_tokens) tok_in = out_tokens + (size_t)s * B;
         }
         if (out_tokens && hipMemcpyAsync(tokens, out_tokens + (size_t)(n_steps - 1) * B, (size_t)B * sizeof(long), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
             return OMR_ERR_LAUNCH;

@@ -85,16 +85,17 @@ class _DecodeLinearArgs(ctypes.Structure):
                 ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("xn_out", ctypes.c_void_p),
                 ("tokens", ctypes.c_void_p), ("emb", ctypes.c_void_p), ("pe_row", ctypes.c_void_p), ("part", ctypes.c_void_p),
                 ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("out0", ctypes.c_void_p), ("ld0", ctypes.c_long),
-                ("out1", ctypes.c_void_p), ("ld1", ctypes.c_long), ("out32", ctypes.c_void_p), ("ld32", ctypes.c_long)]
+                ("out1", ctypes.c_void_p), ("ld1", ctypes.c_long), ("out32", ctypes.c_void_p), ("ld32", ctypes.c_long),
+                ("amax_idx", ctypes.c_void_p), ("amax_val", ctypes.c_void_p), ("amax_part", ctypes.c_void_p)]
 
 
 def decode_linear(w: Tensor, bias: Optional[Tensor], *, x: Optional[Tensor] = None, res: Optional[Tensor] = None, ln=None, tokens: Optional[Tensor] = None,
                   emb: Optional[Tensor] = None, pe_row: Optional[Tensor] = None, part: Optional[Tensor] = None, heads: int = 0, relu: bool = False,
-                  n0: Optional[int] = None, want32: bool = False):
+                  n0: Optional[int] = None, want32: bool = False, want_argmax: bool = False):
     """One linear of a decode position with the preceding element-wise step folded into its input rows (omr_decode_linear):
     x alone -> plain rows; x + res + ln=(gamma, beta, eps) -> LayerNorm(x + res); tokens + emb + pe_row -> embedding row + pe;
     part [M*heads, nsplit, hd+2] + heads -> merged key-split attention.  Returns (out0 [M, n0], out1 [M, N-n0] or None,
-    built rows [M, K] or None, fp32 copy or None)."""
+    built rows [M, K] or None, fp32 copy or None) and, with want_argmax, (first index of the row maximum int64 [M], its value fp32 [M])."""
     require_cuda(w, bias, x, res, tokens, emb, pe_row, part)
     N, K = w.shape
     dt = w.dtype
@@ -130,8 +131,15 @@ def decode_linear(w: Tensor, bias: Optional[Tensor], *, x: Optional[Tensor] = No
         a.out1, a.ld1 = out1.data_ptr(), N - n0
     if out32 is not None:
         a.out32, a.ld32 = out32.data_ptr(), N
+    amax = None
+    if want_argmax:
+        idx = torch.empty(M, dtype=torch.int64, device=w.device)
+        val = torch.empty(M, dtype=torch.float32, device=w.device)
+        part = torch.empty(2 * M * ((N + 15) // 16), dtype=torch.float32, device=w.device)
+        a.amax_idx, a.amax_val, a.amax_part = idx.data_ptr(), val.data_ptr(), part.data_ptr()
+        amax = (idx, val)
     lib().call("omr_decode_linear", ctypes.byref(a), cur_stream())
-    return out0, out1, built, out32
+    return (out0, out1, built, out32) if amax is None else (out0, out1, built, out32, amax)
 
 
 def linear_wgrad_grouped(problems) -> None:

@@ -320,6 +320,9 @@ def test_decode_row_linear_prologues_equal_the_separate_kernels(dtype, M):
     ref = h.float() @ w2.float().t() + b2
     torch.testing.assert_close(torch.cat([o0, o1], 1).float(), ref, **tol)
     assert torch.equal(o32, torch.cat([o0, o1], 1).float())
+    # the greedy pick = first index of the row maximum of the rounded outputs
+    _, _, _, o32b, (idx, val) = K.decode_linear(w2, b2, x=h, n0=d, want32=True, want_argmax=True)
+    assert torch.equal(idx, o32b.argmax(dim=1)) and torch.equal(val, o32b.max(dim=1).values)
     # row independence: the same rows alone
     for i in (0, M - 1):
         a0, a1, _, _ = K.decode_linear(w2, b2, x=h[i:i + 1].contiguous(), n0=d)
