@@ -263,7 +263,7 @@ long omr_decode_workspace_bytes(const omr_decode_desc* desc);
  * amax_idx (nullable): also return, per row, the first index of the largest rounded output and its value (the greedy pick of
  * model.py:187,253): every workgroup leaves its 16-column candidate in amax_part (>= 2 * M * ceil(N/16) floats of scratch) and
  * a second, one-wave-per-row launch reduces them -- cheaper than a pass over the N logits.
- * Requires K % 64 == 0 for prologues 1-3, K <= 2048, 16-byte aligned weight rows. */
+ * Requires K a multiple of 128 (bf16) / 64 (fp32) columns, K <= 2048, 16-byte aligned weight rows. */
 typedef struct omr_decode_linear_args {
     int dtype, pro, M, N, K, relu, n0, nsplit, H, hd, vocab, pad_;
     float eps, pad2_;

@@ -49,10 +49,20 @@ size_t carve(const omr_decode_desc& d, char* base, Ws* w) {
 // batch rows of one position).  Workgroup = 16 output columns x 16 k-lanes; the weight chunks of a thread are requested
 // first, the input rows are built while they fly (LayerNorm of the previous sub-layer / embedding / merge of the key-split
 // attention partials: the element-wise kernels that used to sit between the GEMMs), then a fixed-order fp32 dot product per
-// (row, column): chunks in ascending k, the 16 k-lanes combined by a butterfly.  blockIdx.y picks RM rows; nothing in a row's
+// (row, column): chunks in ascending k, the 16 k-lanes combined by a fixed cross-lane tree.  blockIdx.y picks RM rows; nothing in a row's
 // arithmetic depends on M or on the other rows.
 constexpr int RM = 8, NOUT = 16, KL = 16, WCH = 8;      // rows per workgroup, columns per workgroup, k-lanes, prefetched weight chunks per thread
 constexpr int MAXSPLIT = 32, MAXHS = 256;                // key splits the merge prologue takes (256 keys each: S <= 8192); heads x splits
+
+// Sum over the 16 k-lanes of a column (= one DPP row): four cross-lane adds, every lane ends with the total.  (The generic
+// __shfl_xor butterfly is ~7 instructions per step through the LDS crossbar.)
+__device__ __forceinline__ float klane_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void decode_linear_kernel(omr_decode_linear_args a) {
@@ -64,13 +74,13 @@ __global__ __launch_bounds__(256) void decode_linear_kernel(omr_decode_linear_ar
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = tid / KL, kl = tid % KL;
     const int n = blockIdx.x * NOUT + nl, K = a.K, nch = K / VEC;
     const T* wrow = (const T*)a.w + (long)(n < a.N ? n : 0) * K;
+    // K is a multiple of KL * VEC (host check): chunk kl + i * KL exists for every lane or for none, so the loops over a thread's
+    // chunks have block-uniform bounds and the loads carry no per-lane test (columns past N read row 0 and are never stored)
+    const int cpt = nch / KL;
     F wv[WCH];
 #pragma unroll
-    for (int i = 0; i < WCH; ++i) {
-        const int c = kl + i * KL;
-        wv[i] = frag_zero<T>();
-        if (c < nch && n < a.N) wv[i] = *reinterpret_cast<const F*>(wrow + c * VEC);
-    }
+    for (int i = 0; i < WCH; ++i)
+        if (i < cpt) wv[i] = *reinterpret_cast<const F*>(wrow + (kl + i * KL) * VEC);
     const int per = K / 64;                                              // prologues 1-3: a wave builds a row, lane = `per` consecutive columns
     {
         const int r0 = blockIdx.y * RM, rm = min(RM, a.M - r0);
@@ -146,29 +156,30 @@ __global__ __launch_bounds__(256) void decode_linear_kernel(omr_decode_linear_ar
         float acc[RM];
 #pragma unroll
         for (int r = 0; r < RM; ++r) acc[r] = 0.f;
+        auto slice_rows = [&](auto nr_c) {       // one row (bs 1, the reference's loop) takes the lean single-row body
+            constexpr int NR = decltype(nr_c)::value;
 #pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int c = kl + i * KL;
-            if (c < nch) {
+            for (int i = 0; i < WCH; ++i)
+                if (i < cpt) {
+                    const float* xc = xs + (kl + i * KL) * VEC;
 #pragma unroll
-                for (int r = 0; r < RM; ++r)
-                    if (r < rm)
+                    for (int r = 0; r < NR; ++r)
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) acc[r] = fmaf(to_f32(wv[i][e]), xs[r * K + c * VEC + e], acc[r]);
+                        for (int e = 0; e < VEC; ++e) acc[r] = fmaf(to_f32(wv[i][e]), xc[r * K + e], acc[r]);
+                }
+            for (int i = WCH; i < cpt; ++i) {                            // K beyond the prefetched chunks
+                const F wx = *reinterpret_cast<const F*>(wrow + (kl + i * KL) * VEC);
+                const float* xc = xs + (kl + i * KL) * VEC;
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[r] = fmaf(to_f32(wx[e]), xc[r * K + e], acc[r]);
             }
-        }
-        for (int c = kl + WCH * KL; c < nch; c += KL) {                  // K beyond the prefetched chunks (ff_dim > WCH * KL * VEC)
-            const F wx = n < a.N ? *reinterpret_cast<const F*>(wrow + c * VEC) : frag_zero<T>();
 #pragma unroll
-            for (int r = 0; r < RM; ++r)
-                if (r < rm)
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[r] = fmaf(to_f32(wx[e]), xs[r * K + c * VEC + e], acc[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < RM; ++r)
-#pragma unroll
-            for (int o = KL / 2; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o, 64);
+            for (int r = 0; r < NR; ++r) acc[r] = klane_sum(acc[r]);
+        };
+        if (rm == 1) slice_rows(std::integral_constant<int, 1>());
+        else slice_rows(std::integral_constant<int, RM>());             // rows past rm: arithmetic on stale LDS, never stored
         if (kl == 0 && n < a.N) {
             const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
@@ -231,6 +242,7 @@ extern "C" int omr_decode_linear(const omr_decode_linear_args* ap, void* stream)
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % vec || a.K > 2048 || !a.w || !a.out0 || a.n0 < 0) return OMR_ERR_ARG;
     if (((uintptr_t)a.w & 15) || (a.n0 < a.N && !a.out1)) return OMR_ERR_ARG;
     if (a.pro < 0 || a.pro > 3) return OMR_ERR_ARG;
+    if (a.K % (KL * vec)) return OMR_ERR_UNSUPPORTED;                    // whole 16-lane chunk groups (128 bf16 / 64 fp32 columns)
     if (a.amax_idx && !a.amax_part) return OMR_ERR_ARG;
     if (a.pro && (a.K % 64 || a.K / 64 > 16)) return OMR_ERR_ARG;
     if (a.pro == 1 && a.K != 128 && a.K != 256 && a.K != 512) return OMR_ERR_UNSUPPORTED;      // the widths omr_add_layernorm_fwd takes
@@ -283,7 +295,7 @@ extern "C" int omr_decode_steps(const omr_decode_desc* dp, long* tokens, int t0,
     // three add + LayerNorm, the merge of the key-split attention) is folded into the loading of the NEXT linear's input rows
     // (omr_decode_linear prologues); the residual stream alternates between two buffers because the workgroup that stores a
     // freshly normalised row runs beside workgroups still reading the previous one.
-    if (!d.fp8 && (dm == 128 || dm == 256 || dm == 512) && d.ff <= 2048 && d.ff % 8 == 0 && d.S <= 256 * MAXSPLIT && d.max_len <= 256 * MAXSPLIT) {
+    if (!d.fp8 && (dm == 128 || dm == 256 || dm == 512) && d.ff <= 2048 && d.ff % (16 * (dt == OMR_BF16 ? 8 : 4)) == 0 && d.S <= 256 * MAXSPLIT && d.max_len <= 256 * MAXSPLIT) {
         const long* tok_in = tokens;
         for (int s = 0; s < n_steps; ++s) {
             const int t = t0 + s;

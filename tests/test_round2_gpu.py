@@ -302,7 +302,7 @@ def test_decode_row_linear_prologues_equal_the_separate_kernels(dtype, M):
     a row's result does not depend on how many rows share the launch."""
     from omr_a2s_multimodal_transformer_amd import kernels as K
     g = torch.Generator().manual_seed(31 + M)
-    d, ff, V, H = 128, 320, 77, 4
+    d, ff, V, H = 128, 384, 77, 4
     dev = DEV
     r = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dev).to(dtype)
     w1, b1 = r(ff, d), torch.randn(ff, generator=g).to(dev)
