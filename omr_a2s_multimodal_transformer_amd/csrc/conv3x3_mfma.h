@@ -36,6 +36,11 @@ __device__ __forceinline__ void staged_walk(int pix0, int npix, int DP, int il0,
     }
 }
 
+// halo tile geometry, shared by the kernel and its launcher
+__host__ __device__ constexpr bool conv_subpix(int SH, int SW, int DH, int DW, int RPW) { return DH == 2 && DW == 2 && SH == 1 && SW == 1 && RPW == 2; }
+__host__ __device__ constexpr int conv_halo_h(int TH, int SH, bool subpix) { return subpix ? ((TH - 1) * SH + 3 + 1) / 2 : (TH - 1) * SH + 3; }
+__host__ __device__ constexpr int conv_halo_w(int SW, bool subpix) { return subpix ? ((TW - 1) * SW + 3) / 2 : (TW - 1) * SW + 3; }
+
 struct ConvArgs {
     const void* x; const void* w; const float* bias; void* y;
     const float* mean; const float* rstd;        // [B][CIN] fused InstanceNorm apply on load (or null)
@@ -72,7 +77,10 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2)
     constexpr int CKP = CK + VEC;           // pitch (elements): 16-byte odd multiple -> conflict-free b128 reads
     constexpr int NB = NT / 32;
     constexpr int TH = 4 * RPW;
-    constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3, NPIX = IH * IW;
+    // data gradient of a stride-(2,2) conv (input zero-dilated both ways): only the REAL halo pixels are staged -- rows / columns
+    // of odd tile-local index, (IH, IW) = (5, 17) instead of (10, 34) -- and MFMA blocks are made of one pixel-parity class
+    constexpr bool SUBPIX = conv_subpix(SH, SW, DH, DW, RPW);
+    constexpr int IH = conv_halo_h(TH, SH, SUBPIX), IW = conv_halo_w(SW, SUBPIX), NPIX = IH * IW;
     constexpr int CPP = CK / VEC;           // 16-byte chunks per pixel per channel chunk
     constexpr int OP = NT + VEC;            // output staging pitch (elements)
     // LDS: [Xs | Ws].  The output staging tile Os aliases Xs; when the weights are re-staged per chunk anyway (!SINGLE) it
@@ -89,6 +97,9 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2)
     const T* W = (const T*)a.w;
     constexpr bool single = SINGLE;   // the whole reduction is one channel chunk: weights staged once per block
     const int frow = lane & 31, fk = (lane >> 5) * VEC, hsel = 4 * (lane >> 5);
+    // SUBPIX: MFMA blocks of one pixel-parity class (see the tap loop)
+    const int sp_rp = wave >> 1;                                                 // row parity class of the wave
+    const int sp_row = (wave & 1) * 4 + sp_rp + 2 * (frow >> 4), sp_col = 2 * (frow & 15);   // this lane's tile row / first column
 
     auto stage_weights = [&](int c0) {      // Ws[n][tap][k] for channel chunk c0; 16-byte chunks, loads batched four at a time
         constexpr int NCH = NT * 9 * CPP, ROUNDS = (NCH + 255) / 256, GB = 4;
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2)
         for (int r = 0; r < XR; ++r) {
             const int pix = tid + r * 256;
             const int il = pix / IW, jl = pix - il * IW;
-            const int vh = vh0 + il, vw = vw0 + jl;
+            const int vh = vh0 + (SUBPIX ? 2 * il + 1 : il), vw = vw0 + (SUBPIX ? 2 * jl + 1 : jl);   // SUBPIX: tile origins are odd, real pixels sit at odd offsets
             const bool ok = pix < NPIX && vh >= 0 && vh < Hv && vw >= 0 && vw < Wv && (vh & (DH - 1)) == 0 && (vw & (DW - 1)) == 0;
             const T* src = X + ((long)(vh >> (DH >> 1)) * a.Wr + (vw >> (DW >> 1))) * a.CIN + c0;
 #pragma unroll
@@ -301,6 +312,36 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2)
             for (int i = 0; i < RPW; ++i)
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) row_live[i][kh] = DH == 1 || (((vh0 + (wave * RPW + i) * SH + kh) & (DH - 1)) == 0);
+            if constexpr (SUBPIX) {
+                // Zero-dilated in BOTH directions: three of four halo pixels are structural zeros.  A 32-pixel MFMA block is made of
+                // pixels of ONE (row parity, column parity) class -- the wave owns two tile rows of its parity, block cp takes their
+                // 16 + 16 columns of parity cp -- so every lane of a block agrees on which taps meet real data, and the dead
+                // (tap row, tap column) pairs are skipped for the whole block: 9 MFMAs per 128 pixels and k-step where the
+                // row-contiguous blocks (which can only skip tap rows) issue 18.
+                const int vw0 = ow0 * SW - 1;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int kh = tap / 3, kw = tap % 3;
+                    if (((vh0 + sp_rp + kh) & 1) != 0) continue;                   // wave-uniform: this tap row is all zeros for the wave's rows
+                    const bool lc[2] = {((vw0 + kw) & 1) == 0, ((vw0 + 1 + kw) & 1) == 0};
+#pragma unroll
+                    for (int kk = 0; kk < CK; kk += KStep<T>::value) {
+                        F af[2], bf[NB];
+#pragma unroll
+                        for (int cp = 0; cp < 2; ++cp)
+                            if (lc[cp]) af[cp] = *reinterpret_cast<const F*>(Xs + (long)(((sp_row + kh) >> 1) * IW + ((sp_col + cp + kw) >> 1)) * CKP + kk + fk);
+#pragma unroll
+                        for (int j = 0; j < NB; ++j)
+                            bf[j] = *reinterpret_cast<const F*>(Ws + (long)((j * 32 + frow) * 9 + tap) * CKP + kk + fk);
+#pragma unroll
+                        for (int cp = 0; cp < 2; ++cp) {
+                            if (!lc[cp]) continue;
+#pragma unroll
+                            for (int j = 0; j < NB; ++j) mma32(acc[cp][j], bf[j], af[cp]);
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int kh = tap / 3, kw = tap % 3;
@@ -339,7 +380,7 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2)
         for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
-                T* orow = Os + (long)((wave * RPW + i) * TW + frow) * OP + j * 32 + hsel;
+                T* orow = Os + (long)(SUBPIX ? sp_row * TW + sp_col + i : (wave * RPW + i) * TW + frow) * OP + j * 32 + hsel;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     T4 o;
@@ -417,7 +458,8 @@ template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, b
     ConvArgs a = a0;
     constexpr int TH = 4 * RPW;
     constexpr int CKP = CK + Frag<T>::N;
-    constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3, NPIX = IH * IW, OP = NT + Frag<T>::N;
+    constexpr bool SUBPIX = conv_subpix(SH, SW, DH, DW, RPW);
+    constexpr int IH = conv_halo_h(TH, SH, SUBPIX), IW = conv_halo_w(SW, SUBPIX), NPIX = IH * IW, OP = NT + Frag<T>::N;
     constexpr int XS_ELEMS = (SINGLE && TH * TW * OP > NPIX * CKP) ? TH * TW * OP : NPIX * CKP;
     a.tiles_w = cdiv(a.Wo, TW);
     a.tiles_h = cdiv(a.Ho, TH);
