@@ -556,6 +556,206 @@ __global__ __launch_bounds__(256) void dwconv3x3_walk_kernel(const T* __restrict
     }
 }
 
+// Tile form of the same op (the DSC blocks' 16 x 256 maps): the walker above keeps only two rows of loads in flight per thread
+// and fetches every input element three times (columns j-1, j, j+1), so its 8-row walk is a chain of exposed latencies
+// (1.4 TB/s).  Here a workgroup stages an (8+2) x (TC+2) x C halo tile through LDS -- every element requested once, ALL of a
+// thread's requests in flight together, the InstanceNorm apply and the zero padding done on the way in -- and then each
+// thread produces its (column, channel group)'s 8 outputs from 9 conflict-free 16-byte LDS reads per output against taps
+// held in registers as fp32 (one contiguous 9 x VEC run of the [C][9] weight per thread).
+constexpr int DW_TR = 8;      // output rows per tile
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_tile_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd, const T* __restrict__ mask,
+                                                             float mask_scale, int B, int H, int Wd, int C, int flip) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N, NLD = 16;                    // NLD: 16-byte halo chunks per thread (host guarantees the tile fits)
+    extern __shared__ __attribute__((aligned(16))) unsigned char traw[];
+    T* tile = reinterpret_cast<T*>(traw);                         // [DW_TR + 2][TC + 2][C]
+    const int cv = C / VEC, TC = 256 / cv, IWt = TC + 2;
+    const int tid = threadIdx.x, cg = tid % cv, col = tid / cv, c = cg * VEC;
+    const int tiles_h = cdiv(H, DW_TR);
+    const int b = blockIdx.y / tiles_h, r0 = (blockIdx.y % tiles_h) * DW_TR, j0 = blockIdx.x * TC;
+    const T* xb = x + (long)b * H * Wd * C;
+    // ---- all halo requests of this thread, then the taps, before anything is consumed
+    const int nchunk = (DW_TR + 2) * IWt * cv;
+    F ld[NLD];
+    unsigned okbits = 0;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int ch = tid + i * 256, pp = ch / cv, gi = ch - pp * cv;
+        const int ti = pp / IWt, tj = pp - ti * IWt, r = r0 - 1 + ti, j = j0 - 1 + tj;
+        const bool ok = ch < nchunk && r >= 0 && r < H && j >= 0 && j < Wd;
+        ld[i] = frag_zero<T>();
+        if (ok) ld[i] = *reinterpret_cast<const F*>(xb + ((long)r * Wd + j) * C + gi * VEC);
+        okbits |= (unsigned)ok << i;
+    }
+    F wraw[9];                                                    // w[c*9 .. c*9 + 9*VEC): element e*9 + t is tap t of channel c + e
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wraw[i] = *reinterpret_cast<const F*>(w + (long)c * 9 + i * VEC);
+    float bv[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) bv[e] = bias ? bias[c + e] : 0.f;
+    // ---- normalise on the way into LDS (rounded to T like the MFMA convs; padding stays exactly 0)
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int ch = tid + i * 256;
+        if (ch >= nchunk) break;
+        if (mean && ((okbits >> i) & 1)) {
+            const int gi = ch % cv;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float rs = rstd[b * C + gi * VEC + e], nb = -mean[b * C + gi * VEC + e] * rs;
+                ld[i][e] = from_f32<T>(fmaf(to_f32(ld[i][e]), rs, nb));
+            }
+        }
+        *reinterpret_cast<F*>(tile + (long)ch * VEC) = ld[i];
+    }
+    float wt[9][VEC];
+    auto unpack = [&](auto fl) {                                  // (mirrored taps for the data gradient) -- indices are compile-time
+        constexpr bool FL = decltype(fl)::value;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                constexpr int dummy = 0; (void)dummy;
+                const int idx = e * 9 + (FL ? 8 - t : t);
+                wt[t][e] = to_f32(wraw[idx / VEC][idx % VEC]);
+            }
+    };
+    if (flip) unpack(std::true_type()); else unpack(std::false_type());
+    __syncthreads();
+    const int j = j0 + col;
+    if (j >= Wd) return;
+#pragma unroll 2
+    for (int rr = 0; rr < DW_TR; ++rr) {
+        const int r = r0 + rr;
+        if (r >= H) break;
+        float sacc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sacc[e] = bv[e];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const F xv = *reinterpret_cast<const F*>(tile + ((long)((rr + t / 3) * IWt + col + t % 3) * cv + cg) * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sacc[e] = fmaf(wt[t][e], to_f32(xv[e]), sacc[e]);
+        }
+        const long p = ((long)b * H + r) * Wd + j;
+        F o;
+        if (mask) {
+            const F mk = *reinterpret_cast<const F*>(mask + p * C + c);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(to_f32(mk[e]) > 0.f ? sacc[e] * mask_scale : 0.f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(sacc[e]);
+        }
+        *reinterpret_cast<F*>(y + p * C + c) = o;
+    }
+}
+
+// Weight / bias gradient on the same tile: dW[c][tap] += sum_p dY[p][c] xin[p+tap][c], db[c] += sum_p dY[p][c].  The halo tile
+// of the (normalised) input goes through LDS as above, the thread's 8 dY fragments ride in registers with it (one round
+// trip for everything), 80 fp32 partial sums per thread.  Fold: the columns a wave holds for one channel group sit 16 / 32
+// lanes apart -> v_permlane16_swap / v_permlane32_swap + add; the four waves through LDS; one atomic per weight per
+// workgroup.  (The row walker below keeps a whole image column per thread: 512 workgroups, 7x its HBM time.)
+template <typename T, int NLD>
+__global__ __launch_bounds__(256, 2) void dwconv3x3_wgrad_tile_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd, int B, int H, int Wd, int C) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N;                               // NLD: 16-byte halo chunks per thread (12 for the 128-channel bf16 tile, else 16)
+    extern __shared__ __attribute__((aligned(16))) unsigned char traw[];
+    T* tile = reinterpret_cast<T*>(traw);                         // [DW_TR + 2][TC + 2][C]; afterwards the cross-wave fold scratch
+    const int cv = C / VEC, TC = 256 / cv, IWt = TC + 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cg = tid % cv, col = tid / cv, c = cg * VEC;
+    const int tiles_h = cdiv(H, DW_TR), tiles_w = cdiv(Wd, TC), ntiles = B * tiles_h * tiles_w;
+    const int nchunk = (DW_TR + 2) * IWt * cv;
+    float acc[10][VEC];                                           // [tap 0..8 | bias][channel], kept over all tiles of this workgroup
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
+    // persistent over tiles: the fold and the atomics at the end are paid once per workgroup (a memory-side float atomic
+    // serialises per cache line -- one per tile was 1.3 M atomics onto 40 lines, 3x the time of everything else)
+    for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+        const int b = tile_id / (tiles_h * tiles_w), rem = tile_id - b * tiles_h * tiles_w;
+        const int r0 = (rem / tiles_w) * DW_TR, j0 = (rem % tiles_w) * TC, j = j0 + col;
+        const T* xb = x + (long)b * H * Wd * C;
+        F ld[NLD];
+        unsigned okbits = 0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int ch = tid + i * 256, pp = ch / cv, gi = ch - pp * cv;
+            const int ti = pp / IWt, tj = pp - ti * IWt, r = r0 - 1 + ti, jj = j0 - 1 + tj;
+            const bool ok = ch < nchunk && r >= 0 && r < H && jj >= 0 && jj < Wd;
+            ld[i] = frag_zero<T>();
+            if (ok) ld[i] = *reinterpret_cast<const F*>(xb + ((long)r * Wd + jj) * C + gi * VEC);
+            okbits |= (unsigned)ok << i;
+        }
+        const T* dyp = dy + (((long)b * H + r0) * Wd + j) * C + c;   // this thread's dY fragments, one row ahead of their use
+        auto load_gy = [&](int rr) { return (j < Wd && r0 + rr < H) ? *reinterpret_cast<const F*>(dyp + (long)rr * Wd * C) : frag_zero<T>(); };
+        F gnext = load_gy(0);
+        __syncthreads();                                          // the previous tile's reads are done
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int ch = tid + i * 256;
+            if (ch < nchunk) {
+                if (mean && ((okbits >> i) & 1)) {
+                    const int gi = ch % cv;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float rs = rstd[b * C + gi * VEC + e], nb = -mean[b * C + gi * VEC + e] * rs;
+                        ld[i][e] = from_f32<T>(fmaf(to_f32(ld[i][e]), rs, nb));
+                    }
+                }
+                *reinterpret_cast<F*>(tile + (long)ch * VEC) = ld[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int rr = 0; rr < DW_TR; ++rr) {                      // zero dY fragments (rows / columns past the image) add nothing
+            const F gcur = gnext;
+            if (rr + 1 < DW_TR) gnext = load_gy(rr + 1);
+            float g[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { g[e] = to_f32(gcur[e]); acc[9][e] += g[e]; }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const F xv = *reinterpret_cast<const F*>(tile + ((long)((rr + t / 3) * IWt + col + t % 3) * cv + cg) * VEC);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[t][e] = fmaf(g[e], to_f32(xv[e]), acc[t][e]);
+            }
+        }
+    }
+    // ---- fold the columns of this wave that share the channel group (lanes cv apart: cv = 16 or 32; cv >= 64: one column per wave)
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            if (cv <= 32) acc[t][e] += __shfl_xor(acc[t][e], 32, 64);
+            if (cv == 16) acc[t][e] += __shfl_xor(acc[t][e], 16, 64);
+        }
+    // ---- the waves through LDS (the tile is dead), then one atomic per weight per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(traw);                  // [wave-slot][cg][10][VEC]
+    const bool wide = cv >= 64;                                   // a column spans whole waves: every thread is the only holder of its (column, group)
+    const int slot = wide ? col : wave, nslot = wide ? TC : 4;
+    if (wide || lane < cv) {
+        float* rp = red + ((long)slot * cv + cg) * 10 * VEC;
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) rp[t * VEC + e] = acc[t][e];
+    }
+    __syncthreads();
+    for (int i = tid; i < cv * 10 * VEC; i += 256) {
+        float v = 0.f;
+        for (int sl = 0; sl < nslot; ++sl) v += red[(long)sl * cv * 10 * VEC + i];
+        const int g2 = i / (10 * VEC), rem = i - g2 * 10 * VEC, t = rem / VEC, e = rem - t * VEC, ch = g2 * VEC + e;
+        if (t < 9) atomicAdd(&dw[(long)ch * 9 + t], v);
+        else if (db) atomicAdd(&db[ch], v);
+    }
+}
+
 // dW[c][tap] += sum_p dY[p][c] xin[p+tap][c];  db[c] += sum_p dY[p][c].
 // Thread = (image column j, channel group): it walks DOWN the rows of one image with a 3x3 register window of the
 // normalised input (kept in the compute dtype) -- per pixel 3 new 16-byte x loads + 1 dY load, issued a row ahead of their
@@ -750,7 +950,24 @@ extern "C" int omr_dwconv3x3(int dtype, const void* x, const void* w, const floa
     const int vec = dtype == OMR_BF16 ? 8 : 4;
     if (C % vec) return OMR_ERR_UNSUPPORTED;
     const int cv = C / vec;
-    if (cv <= 256 && 256 % cv == 0 && H >= 4 && (size_t)10 * C * sizeof(float) <= 48 * 1024) {      // row walker (DSC blocks)
+    const size_t esz = dtype == OMR_BF16 ? 2 : 4;
+    const int tc = cv <= 256 && 256 % cv == 0 ? 256 / cv : 0;
+    const size_t tile_bytes = (size_t)(DW_TR + 2) * (tc + 2) * C * esz;
+    if (tc >= 2 && H >= 4 && tile_bytes <= 64 * 1024 && (DW_TR + 2) * (tc + 2) * cv <= 16 * 256 && ((uintptr_t)w & 15) == 0) {      // LDS tile (DSC blocks)
+        static std::atomic<int> opt_in{0};                           // large-LDS opt-in issued once per dtype (0 -> set only)
+        const int bit = dtype == OMR_BF16 ? 1 : 2;
+        if (tile_bytes > 32 * 1024 && !(opt_in.load(std::memory_order_acquire) & bit)) {
+            const void* kern = dtype == OMR_BF16 ? (const void*)dwconv3x3_tile_kernel<bf16> : (const void*)dwconv3x3_tile_kernel<float>;
+            if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return OMR_ERR_LAUNCH;
+            opt_in.fetch_or(bit, std::memory_order_release);
+        }
+        dim3 gridt(cdiv(W, tc), B * cdiv(H, DW_TR));
+        DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_tile_kernel<T>), gridt, 256, tile_bytes, (hipStream_t)stream, (const T*)x, (const T*)w, bias, (T*)y, in_mean, in_rstd,
+                                             (const T*)out_mask, mask_scale, B, H, W, C, flip));
+        OMR_CHECK_LAUNCH();
+        return OMR_OK;
+    }
+    if (cv <= 256 && 256 % cv == 0 && H >= 4 && (size_t)10 * C * sizeof(float) <= 48 * 1024) {      // row walker (tiles that do not fit the LDS budget)
         int RC = 8;                                              // rows per thread: 2 halo rows re-read per RC
         while (RC < H && (long)cdiv(W, 256 / cv) * B * cdiv(H, RC) > 4096) RC *= 2;
         dim3 gridw(cdiv(W, 256 / cv), B * cdiv(H, RC));
@@ -772,6 +989,35 @@ extern "C" int omr_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, flo
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return OMR_ERR_ARG;
     const int vec = dtype == OMR_BF16 ? 8 : 4;
     if (C % vec || 256 % (C / vec)) return OMR_ERR_UNSUPPORTED;
+    {
+        const size_t esz = dtype == OMR_BF16 ? 2 : 4;
+        const int cv = C / vec, tc = cv <= 256 && 256 % cv == 0 ? 256 / cv : 0;
+        size_t tile_bytes = (size_t)(DW_TR + 2) * (tc + 2) * C * esz;
+        const size_t red_bytes = (size_t)(cv >= 64 ? tc : 4) * cv * 10 * vec * sizeof(float);
+        if (red_bytes > tile_bytes) tile_bytes = red_bytes;
+        if ((cv == 16 || cv == 32 || (cv >= 64 && cv <= 256)) && tc >= 1 && H >= 4 && tile_bytes <= 64 * 1024 && (DW_TR + 2) * (tc + 2) * cv <= 16 * 256) {
+            static std::atomic<int> opt_in{0};
+            const int bit = dtype == OMR_BF16 ? 1 : 2;
+            if (tile_bytes > 32 * 1024 && !(opt_in.load(std::memory_order_acquire) & bit)) {
+                const void* k12 = dtype == OMR_BF16 ? (const void*)dwconv3x3_wgrad_tile_kernel<bf16, 12> : (const void*)dwconv3x3_wgrad_tile_kernel<float, 12>;
+                const void* k16 = dtype == OMR_BF16 ? (const void*)dwconv3x3_wgrad_tile_kernel<bf16, 16> : (const void*)dwconv3x3_wgrad_tile_kernel<float, 16>;
+                if (hipFuncSetAttribute(k12, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute(k16, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return OMR_ERR_LAUNCH;
+                opt_in.fetch_or(bit, std::memory_order_release);
+            }
+            const long ntiles = (long)cdiv(W, tc) * B * cdiv(H, DW_TR);
+            dim3 gridt((unsigned)(ntiles < 256 ? ntiles : 256));       // persistent: one workgroup per CU (the closing atomics are per workgroup)
+            if ((DW_TR + 2) * (tc + 2) * cv <= 12 * 256) {
+                DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_wgrad_tile_kernel<T, 12>), gridt, 256, tile_bytes, (hipStream_t)stream, (const T*)x, (const T*)dy, dw, db, in_mean,
+                                                     in_rstd, B, H, W, C));
+            } else {
+                DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_wgrad_tile_kernel<T, 16>), gridt, 256, tile_bytes, (hipStream_t)stream, (const T*)x, (const T*)dy, dw, db, in_mean,
+                                                     in_rstd, B, H, W, C));
+            }
+            OMR_CHECK_LAUNCH();
+            return OMR_OK;
+        }
+    }
     long total = (long)B * H * W;
     const int ncg = C / vec;
     if (ncg > 64 || 64 % ncg) return OMR_ERR_UNSUPPORTED;          // a wave holds whole channel-group sets

@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void instnorm_bwd_apply_kernel(const T* __rest
     const long p0 = (long)blockIdx.x * pix_per_block;
     const long p1 = p0 + pix_per_block < HW ? p0 + pix_per_block : HW;
     const long base = (long)b * HW * C + cg * VEC;
+#pragma unroll 4
     for (long p = p0 + phase; p < p1; p += nphase) {
         const F gv = *reinterpret_cast<const F*>(g + base + p * C), xv = *reinterpret_cast<const F*>(x + base + p * C);
         F o;
