@@ -50,7 +50,11 @@ __device__ uint4 g_zero16;   // 16 zero bytes in global memory: the DMA source o
 // find the source of an LDS slot.
 template <int CB, int PS> struct Place {
     static constexpr int CPP = CB / 8;
-    __device__ static __forceinline__ int pixel(int pix) { return (PS == 2 && CB >= 32) ? pix ^ ((pix >> 2) & 1) : pix; }
+    // 32-byte rows (CB = 16): the two halves of a wave read pixels 16 apart (paired k-steps, see the kernel) -- 512 bytes, the
+    // same banks -- so every other group of 16 pixels has its aligned pixel quads swapped in pairs (+-128 bytes)
+    __device__ static __forceinline__ int pixel(int pix) {
+        return CB == 16 ? pix ^ (((pix >> 4) & 1) << 2) : (PS == 2 && CB >= 32) ? pix ^ ((pix >> 2) & 1) : pix;
+    }
     __device__ static __forceinline__ int chunk(int pix, int c) { return CB == 64 ? c ^ (((pix >> 1) & 1) << 2) : c; }
     // element offset of channel ch of pixel pix
     __device__ static __forceinline__ int off(int pix, int ch) { return pixel(pix) * CB + ((chunk(pix, ch >> 3) << 3) | (ch & 7)); }
@@ -63,7 +67,7 @@ template <int CB, int PS> struct Place {
 
 template <int CB, int NPIXT, int NTHR> struct TileDma {
     // the placement may swap a pixel with its pair neighbour, so slots exist for an even number of pixels
-    static constexpr int CPP = CB / 8, NCH = (NPIXT + 1) / 2 * 2 * CPP, ROUNDS = (NCH + NTHR - 1) / NTHR;
+    static constexpr int CPP = CB / 8, NCH = (CB == 16 ? (NPIXT + 7) / 8 * 8 : (NPIXT + 1) / 2 * 2) * CPP, ROUNDS = (NCH + NTHR - 1) / NTHR;
     static constexpr int ELEMS = (NCH + 63) / 64 * 64 * 8;   // LDS footprint: whole wave instructions (tail lanes fetch zeros)
 };
 
@@ -125,6 +129,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
     constexpr int YS = DY_::ELEMS, BUF = YS + DX_::ELEMS;              // elements per ring slot
     constexpr int DMA_PER_TILE = DY_::ROUNDS + DX_::ROUNDS;
     constexpr int KUNROLL = NPY / 16 / WK <= 2 ? 2 : 1;     // k-steps per wave per tile: unroll the short loops only (register budget)
+    static_assert(NPY % 32 == 0, "a tile row is 32 pixels: paired k-steps stay inside a row");
     static_assert(WK >= 1 && WN * WC * WK == NW && NSTAGE >= 2, "wave split / ring depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* ring = reinterpret_cast<bf16*>(smem_raw);                      // [NSTAGE][BUF]
@@ -192,9 +197,15 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
 
     // lane roles of the transposing reads (scratch/trtest.hip): lane (q, p, cb, hh) addresses pixel row q, channels
     // 16 cb + 4 p of its 16-lane group and receives 4 consecutive pixels of channel 16 cb + (lane & 15)
-    const int q = (lane & 15) >> 2, cb = (lane >> 4) & 1, chan = cb * 16 + (lane & 3) * 4, hh = lane >> 5;
-    // 16-channel operands: lanes with cb = 1 read the neighbouring pixel's bytes (valid LDS).  They only feed rows / columns
-    // >= 16 of the 32x32 product, which the epilogue never stores -- no masking and no divergent reads.
+    // 16 x 16 channels (PAIR): the cb = 1 half of the wave would only feed rows / columns >= 16 of the 32x32 product, which
+    // nobody wants.  It takes the NEXT 16 pixels of the tile row instead, same 16 channels: the product becomes block diagonal
+    // -- D[0:16][0:16] sums pixels k0..k0+15, D[16:32][16:32] sums k0+16..k0+31 -- so one MFMA and one pair of LDS reads
+    // cover 32 pixels (the kernel is bound by its ds_read_tr traffic: half the reads, half the MFMAs); the epilogue adds
+    // the two diagonal blocks.  Mixed 16/32 tiles keep the plain form: cb = 1 lanes of the 16-channel operand read the
+    // neighbouring pixel's bytes (valid LDS) into rows / columns the epilogue never stores.
+    constexpr bool PAIR = CBN == 16 && CBC == 16;
+    constexpr int KS = PAIR ? 32 : 16;                           // pixels per k-step
+    const int q = (lane & 15) >> 2, cb = (lane >> 4) & 1, chan = (PAIR ? 0 : cb * 16) + (lane & 3) * 4, hh = lane >> 5;
     const int cha = (CBN >= 32 ? wn * 32 : 0) + chan, chb = (CBC >= 32 ? wc * 32 : 0) + chan;
 
     int tile = blockIdx.x;
@@ -259,8 +270,8 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
             for (int pix = tid / CBN; pix < NPY; pix += NPH) bsum += (float)Ys[PY::off(pix, ch)];
         }
 #pragma unroll KUNROLL
-        for (int k0 = wk * 16; k0 < (DBG(2) ? 0 : NPY); k0 += WK * 16) {
-            const int pk = k0 + 8 * hh + q;                  // pixels pk..pk+3 (u = 0) and pk+4..pk+7 (u = 1), same tile row
+        for (int k0 = wk * KS; k0 < (DBG(2) ? 0 : NPY); k0 += WK * KS) {
+            const int pk = k0 + (PAIR ? 16 * cb : 0) + 8 * hh + q;   // pixels pk..pk+3 (u = 0) and pk+4..pk+7 (u = 1), same tile row
             const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(Ys + PY::off(pk, cha)));
             const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(Ys + PY::off(pk + 4, cha)));
             const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
@@ -311,7 +322,12 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
             const int gwn = g / WC, gwc = g % WC;
             const int cl = ln & 31, nl = acc_row(r, ln);
             const int c = c0 + (CBC >= 32 ? gwc * 32 : 0) + cl, n = n0 + (CBN >= 32 ? gwn * 32 : 0) + nl;
-            if (c < a.CIN && n < a.COUT && (CBC >= 32 || cl < 16) && (CBN >= 32 || nl < 16)) atomicAdd(&a.dw[((long)n * 9 + tap) * a.CIN + c], v);
+            if constexpr (CBN == 16 && CBC == 16) {        // the two diagonal 16x16 blocks hold the two pixel halves of every k-step
+                if ((cl < 16) == (nl < 16)) {
+                    const int c2 = c0 + (cl & 15), n2 = n0 + (nl & 15);
+                    if (c2 < a.CIN && n2 < a.COUT) atomicAdd(&a.dw[((long)n2 * 9 + tap) * a.CIN + c2], v);
+                }
+            } else if (c < a.CIN && n < a.COUT && (CBC >= 32 || cl < 16) && (CBN >= 32 || nl < 16)) atomicAdd(&a.dw[((long)n * 9 + tap) * a.CIN + c], v);
         }
     }
 }
