@@ -83,7 +83,9 @@ class Conv3x3Fn(Function):
         g = gy.contiguous()
         if relu and mask_own:
             g = K.relu_bwd(g, y, own_scale)        # y is the stored (dropped) output: (y > 0) * 1/(1-p) is ReLU + dropout backward
-        K.conv3x3_wgrad(x, g, weight.omr_grad, stride=stride, in_stats=stats, db=bias.omr_grad)   # fills every CU's LDS: nothing to gain on the side stream (measured)
+        # one workgroup per CU with a full LDS ring: little can run beside it, but its ramp-up / drain overlaps the data gradient's
+        # (28.37 -> 28.17 ms per C2 step; a shallower ring that leaves LDS for the neighbour loses more than it gains: 28.4)
+        WgradStream.run("conv", lambda: K.conv3x3_wgrad(x, g, weight.omr_grad, stride=stride, in_stats=stats, db=bias.omr_grad), x, g, *(stats or ()))
         dx = None
         if ctx.needs_input_grad[0]:
             wd = K.conv3x3_weight_flip(wt(weight, x.dtype))

@@ -90,7 +90,7 @@ class WgradStream:
     errors in the point_conv weight gradients in front of the encoder's residual adds when the side stream lags)."""
 
     enabled = True
-    kinds = {"linear", "depthwise", "cross_kv"}     # which weight gradients take the side stream (tests narrow this)
+    kinds = {"linear", "depthwise", "cross_kv", "conv"}     # which weight gradients take the side stream (tests narrow this)
     _side = {}
     _pending = {}          # device index -> the stream that has to wait
     _hold = []             # (event recorded behind the side-stream kernel, the tensors it reads)
