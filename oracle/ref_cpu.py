@@ -545,6 +545,50 @@ def log_stft(y, n_fft: int = 2048, hop: int = 512, sr: int = 22050, fmax: float 
     return (db / 80.0 + 1.0).astype(np.float32)
 
 
+def resample_poly(y, orig_sr: int, target_sr: int):
+    """Polyphase sample-rate conversion, the first line of get_spectrogram_from_raw_audio (src/data/preprocessing.py:19:
+    librosa.resample(raw_audio, orig_sr=sr, target_sr=22050)).  This restates librosa's res_type="polyphase" =
+    scipy.signal.resample_poly(y, up, down) (scipy/signal/_signaltools.py): a Kaiser(beta = 5) windowed-sinc low-pass of
+    2 * 10 * max(up, down) + 1 taps at cutoff 1 / max(up, down), scaled by `up`, applied to the zero-stuffed signal with zero
+    ("constant") edges, output length ceil(n * up / down).  Pinned against scipy itself (tests/golden/f18_resample.npz).
+    PARITY UNPINNED with respect to the reference's call: librosa's DEFAULT res_type is "soxr_hq" (the soxr library, absent
+    here, algorithm not restated), so the reference's own samples differ from these at the filter-design level."""
+    import math
+    import numpy as np
+    y = np.asarray(y, dtype=np.float64)
+    g = math.gcd(int(orig_sr), int(target_sr))
+    up, down = int(target_sr) // g, int(orig_sr) // g
+    if up == down:
+        return y.astype(np.float32)
+    h, r0 = resample_filter(up, down)
+    n_out = -(-len(y) * up // down)
+    out = np.zeros(n_out)
+    for n in range(n_out):                       # y[n] = sum_i x[i] h[(n + r0) * down - i * up]
+        t = (n + r0) * down
+        i_lo = max(0, -(-(t - len(h) + 1) // up))
+        i_hi = min(len(y) - 1, t // up)
+        if i_hi >= i_lo:
+            i = np.arange(i_lo, i_hi + 1)
+            out[n] = np.dot(y[i], h[t - i * up])
+    return out.astype(np.float32)
+
+
+def resample_filter(up: int, down: int):
+    """(taps h with scipy's leading zero padding, samples n_pre_remove dropped from the filtered signal) of
+    scipy.signal.resample_poly(window=("kaiser", 5.0)); firwin restated: h = c sinc(c m) kaiser(N, 5), unit DC gain, times up."""
+    import numpy as np
+    max_rate = max(up, down)
+    half_len = 10 * max_rate
+    ntaps = 2 * half_len + 1
+    c = 1.0 / max_rate
+    m = np.arange(ntaps) - half_len
+    h = c * np.sinc(c * m) * np.kaiser(ntaps, 5.0)
+    h = h / h.sum() * up
+    n_pre_pad = down - half_len % down
+    h = np.concatenate([np.zeros(n_pre_pad), h])
+    return h, (half_len + n_pre_pad) // down
+
+
 # --------------------------------------------------------------------------------------
 # score-image front end (src/data/preprocessing.py:44-52)
 # --------------------------------------------------------------------------------------

@@ -242,3 +242,11 @@ def test_f17_adam_skips_parameters_without_gradient(golden):
     names = list(sd.keys())
     assert steps[names.index("decoder.out_layer.bias")] == 5 and steps[names.index("image_encoder.conv_blocks.0.conv1.weight")] == 4
     assert steps[names.index("audio_encoder.conv_blocks.0.conv1.weight")] == 3 and steps[names.index("cross_attn.attention.in_proj_weight")] == 2
+
+
+def test_f18_resample_oracle_equals_scipy(golden):
+    """oracle.resample_poly (restated scipy.signal.resample_poly = librosa res_type="polyphase") against scipy's own outputs."""
+    g = golden("f18_resample")
+    for k in range(6):
+        o, t, _ = (int(v) for v in g[f"c{k}_meta"])
+        np.testing.assert_allclose(R.resample_poly(g[f"c{k}_x"], o, t), g[f"c{k}_y"], rtol=0, atol=2e-6)
