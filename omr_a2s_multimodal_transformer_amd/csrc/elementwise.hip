@@ -119,6 +119,27 @@ template <typename T> __global__ void add_pe2d_kernel(const T* __restrict__ x, c
         out[i] = from_f32<T>(to_f32(x[i]) + pe[((long)ii * maxw + j) * C + c]);
     }
 }
+// the same with 16-byte fragments (C a multiple of the fragment width, 16-byte aligned tensors): one index decode per fragment
+template <typename T> __global__ void add_pe2d_vec_kernel(const T* __restrict__ x, const float* __restrict__ pe, T* __restrict__ out,
+                                                          int B, int h, int w, int C, int maxw) {
+    typedef typename Frag<T>::type F;
+    constexpr int VEC = Frag<T>::N;
+    const int cv = C / VEC;
+    const long total = (long)B * h * w * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VEC; const long p = i / cv; const int j = (int)(p % w); const long q = p / w; const int ii = (int)(q % h);
+        const F xv = *reinterpret_cast<const F*>(x + p * C + c);
+        const float* pp = pe + ((long)ii * maxw + j) * C + c;
+        F o;
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(pp + e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[e + k] = from_f32<T>(to_f32(xv[e + k]) + pv[k]);
+        }
+        *reinterpret_cast<F*>(out + p * C + c) = o;
+    }
+}
 
 // ---------------------------------------------------------------- column sums:  db[n] += sum_m dY[m, n]   (bias gradients)
 // Block = 64 columns x 4 row phases over a slab of rows; LDS combine, one fp32 atomic per column per block.
@@ -369,6 +390,12 @@ extern "C" int omr_add_pe2d(int dtype, const void* x, const float* pe_hwc, void*
                             void* stream) {
     if (B <= 0 || h <= 0 || w <= 0 || C <= 0) return OMR_ERR_ARG;
     if (h > maxh || w > maxw) return OMR_ERR_ARG;  // feature map larger than the PE table
+    const int vec = dtype == OMR_BF16 ? 8 : 4;
+    if (C % vec == 0 && !(((uintptr_t)x | (uintptr_t)out | (uintptr_t)pe_hwc) & 15)) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((add_pe2d_vec_kernel<T>), ew_grid((long)B * h * w * (C / vec)), EW_BLOCK, 0, (hipStream_t)stream, (const T*)x, pe_hwc, (T*)out, B, h, w, C, maxw));
+        OMR_CHECK_LAUNCH();
+        return OMR_OK;
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL((add_pe2d_kernel<T>), ew_grid((long)B * h * w * C), EW_BLOCK, 0, (hipStream_t)stream, (const T*)x, pe_hwc, (T*)out, B, h, w, C, maxw));
     OMR_CHECK_LAUNCH();
     return OMR_OK;
