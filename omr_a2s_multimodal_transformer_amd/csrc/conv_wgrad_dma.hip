@@ -372,8 +372,10 @@ template <int SH, int SW, bool NORM> int pick(const WgradArgs& a, hipStream_t s)
         if (cn == 64 && cc == 64) return launch<64, 64, 8, 1, 1, 8, 2, NORM>(a, s);
         if (cn == 64 && cc == 32) return launch<64, 32, 8, 1, 1, 8, 2, NORM>(a, s);
         if (cn == 32 && cc == 64) return launch<32, 64, 8, 1, 1, 8, 2, NORM>(a, s);
-        if (cn == 32 && cc == 32) return launch<32, 32, 8, 1, 1, 8, 4, NORM>(a, s);
-        if (cn == 32 && cc == 16) return launch<32, 16, 8, 1, 1, 8, 5, NORM>(a, s);
+        // 32-channel tiles: TWO 4-wave workgroups per CU with a 2-deep ring each (one's DMA wait behind the other's MFMA loop:
+        // 726 -> 648 us and 730 -> 695 us against one 8-wave workgroup with a 4-5 deep ring; the paired 16x16 form loses: 383 -> 594)
+        if (cn == 32 && cc == 32) return launch<32, 32, 8, 1, 1, 4, 2, NORM>(a, s);
+        if (cn == 32 && cc == 16) return launch<32, 16, 8, 1, 1, 4, 2, NORM>(a, s);
         if (cn == 16 && cc == 16) return launch<16, 16, 8, 1, 1, 8, 6, NORM>(a, s);
     }
     if constexpr (SH == 2 && SW == 2) {   // input tile is 4x the output tile: fewer rows per tile
