@@ -217,8 +217,9 @@ def decode_rate(model, x1, steps=96):
 def roofline_dominant_kernel(B, H, W, dtype):
     """Dominant kernel of the step (profiles/): conv3x3_mfma on conv_blocks.1.conv2 (32->32 channels at full resolution) --
     the largest single contraction of the encoder -- IN THE INSTANTIATION THE TRAINING STEP RUNS: bias + ReLU + fused
-    MixDropout + fused InstanceNorm statistics of the output (template EPI = 1; the bias/ReLU-only EPI = 0 variant serves the
-    masked data gradient).  Timed live with HIP events on the launch stream.  Algorithmic bytes per launch (SURVEY.md section
+    InstanceNorm statistics of the output (template EPI = 1; with the block's MixDropout on this conv, one step in three, the
+    EPI = 3 variant, timed as well; the bias/ReLU-only EPI = 0 variant serves the masked data gradient).  Timed live with HIP
+    events on the launch stream.  Algorithmic bytes per launch (SURVEY.md section
     8d accounting: read the input once, write the output once, weights and statistics negligible) = B*H*W*(Cin + Cout)*sizeof;
     algorithmic flops = 2*9*Cin*Cout*B*H*W."""
     from omr_a2s_multimodal_transformer_amd import kernels as K
@@ -235,7 +236,7 @@ def roofline_dominant_kernel(B, H, W, dtype):
         for _ in range(3):
             launch()
         torch.cuda.synchronize()
-        n = 8
+        n = 16
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(n):
