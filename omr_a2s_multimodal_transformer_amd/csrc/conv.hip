@@ -1018,7 +1018,6 @@ extern "C" int omr_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, flo
             return OMR_OK;
         }
     }
-    long total = (long)B * H * W;
     const int ncg = C / vec;
     if (ncg > 64 || 64 % ncg) return OMR_ERR_UNSUPPORTED;          // a wave holds whole channel-group sets
     dim3 grid(cdiv(W, 256 / ncg), B);

@@ -159,7 +159,6 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
                                                          float* __restrict__ rstd, long M, float eps, uint32_t drop_thresh, float drop_scale,
                                                          uint64_t drop_seed) {
     typedef __attribute__((ext_vector_type(PER))) T VT;
-    typedef __attribute__((ext_vector_type(PER))) float VF;
     constexpr int d = PER * 64;
     const int lane = threadIdx.x & 63;
     const long row = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -304,7 +303,6 @@ extern "C" int omr_instnorm_stats(int dtype, const void* x, float* mean, float* 
     dim3 grid(cdiv(HW, ppb), B);
     DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_partial_kernel<T, false>), grid, 256, partial_lds_bytes(dtype), s, (const T*)x, (const T*)nullptr,
                                          (const float*)nullptr, (const float*)nullptr, (double*)workspace, HW, C, ppb));
-    long n = (long)B * C;
     hipLaunchKernelGGL((instnorm_reduce_slots_kernel<true>), B, 256, 0, s, (const double*)workspace, (int)grid.x, C, mean, rstd, (double*)nullptr, 1.0 / (double)HW, eps);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
@@ -313,7 +311,6 @@ extern "C" int omr_instnorm_stats(int dtype, const void* x, float* mean, float* 
 /* mean / rstd from the fp64 {sum, sum of squares} slots that a producer kernel filled (omr_conv3x3_fwd stat_mode 1) */
 extern "C" int omr_instnorm_finalize(const void* workspace, int slots, float* mean, float* rstd, int B, long HW, int C, float eps, void* stream) {
     if (B <= 0 || HW <= 0 || C <= 0 || slots < 1 || !workspace) return OMR_ERR_ARG;
-    long n = (long)B * C;
     hipLaunchKernelGGL((instnorm_reduce_slots_kernel<true>), B, 256, 0, (hipStream_t)stream, (const double*)workspace, slots, C, mean, rstd, (double*)nullptr, 1.0 / (double)HW, eps);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
@@ -322,7 +319,6 @@ extern "C" int omr_instnorm_finalize(const void* workspace, int slots, float* me
 static int launch_bwd_apply(int dtype, const void* dxhat, const void* x, const float* mean, const float* rstd, void* dx, int B, long HW, int C,
                             int relu_mask, float relu_scale, double* ws, int slots, hipStream_t s) {
     double* compact = ws + (long)B * slots * C * 2;
-    long n = (long)B * C;
     hipLaunchKernelGGL((instnorm_reduce_slots_kernel<false>), B, 256, 0, s, (const double*)ws, slots, C, (float*)nullptr, (float*)nullptr, compact, 0.0, 0.f);
     int ppb2 = 1024;
     dim3 grid2(cdiv(HW, ppb2), B);
