@@ -64,7 +64,13 @@ def main():
     ap.add_argument("--dtype", default="", choices=["", "bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="rehearse the multi-rank launch on the CPU: gloo group, no GPU work, prints the JSON contract with value 0")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))       # BEFORE anything touches the GPU: the ranks are child processes, never an exec
+    if args.dry_launch:
+        return dry_launch(args)
     c = dict(CONFIGS[args.config])
     if args.batch:
         c["batch"] = args.batch
@@ -82,6 +88,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -181,6 +190,57 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run as a CHILD
+    process with the same arguments, relay its output (rank 0 prints the JSON line) and return its exit code.  Lightning
+    starts the reference's ranks the same way (train.py:140-154: Trainer(devices=..., strategy=ddp) spawns them)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch(args):
+    """CPU rehearsal of the launch contract (tests/test_bench_launch_cpu.py): the ranks form a gloo group, agree on the world
+    size, run the barrier + MAX-over-ranks timing protocol around an empty region and rank 0 prints the JSON line."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    elapsed = time.perf_counter() - t0
+    seen = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seen)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "training samples/sec", "value": 0.0, "unit": "samples/s", "n_gpus": world, "ranks_seen": int(seen.item()),
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "none (dry launch)", "config": {"workload": "dry launch", "parallelism": f"dp{world}"}}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def decode_rate(model, x1, steps=96):

@@ -37,6 +37,7 @@ class GradReducer:
         self.handles: List = []
         self.use_stream = async_stream and flat.grad.is_cuda
         self.stream = torch.cuda.Stream(device=flat.device) if self.use_stream else None
+        self.shared_rng = None            # random.Random every rank seeds with rank 0's value (broadcast_state): rank-proof host decisions
 
     def broadcast_state(self) -> None:
         """Rank 0's master parameters (and Adam moments, if an optimizer exists already) to every rank, then refresh the bf16
@@ -44,10 +45,20 @@ class GradReducer:
         loaded."""
         if self.world == 1:
             return
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
         for t in (self.flat.master, self.flat.exp_avg, self.flat.exp_avg_sq):
             if t is not None:
-                dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                dist.broadcast(t, src=src, group=self.group)
         self.flat.sync_lowp()
+        # Host decisions that select WHICH parameters a step touches (MultimodalTransformer's modality drop, model.py:561-575)
+        # must come out the same on every rank: the all-reduced buckets carry every rank's gradients, so a rank that skipped
+        # `audio_encoder` in its optimizer while another rank trained it would diverge silently.  The reference's ranks agree
+        # only because train.py:17 seeds every process alike; here the ranks draw such decisions from ONE generator seeded
+        # with rank 0's value -- a one-time broadcast, no per-step collective, no host synchronisation.
+        import random
+        seed = torch.tensor([random.getrandbits(62)], dtype=torch.int64, device=self.flat.master.device)
+        dist.broadcast(seed, src=src, group=self.group)
+        self.shared_rng = random.Random(int(seed.item()))
 
     @property
     def grad_scale(self) -> float:

@@ -409,7 +409,7 @@ class MultimodalTransformer(_Base):
         xi, xa = self._boundary(xi, xa)
         self._touched = None           # which sub-modules get gradients this step: the optimizer skips the others (FusedAdam)
         if apply_teacher_forcing_modality:
-            modality = self.apply_teacher_forcing_modality()
+            modality = self._draw_modality()
             if modality == "image":
                 self._touched = ("image_encoder", "decoder")
                 return xi, xli
@@ -440,6 +440,17 @@ class MultimodalTransformer(_Base):
         if random.random() < self.teacher_forcing_modality_prob:
             return "image" if random.random() < 0.5 else "audio"
         return "both"
+
+    def _draw_modality(self) -> str:
+        """The modality decision of a training step.  Single process: the reference's draws from the global `random` stream.
+        Data parallel: the global draws are still consumed (the stream stays where the reference's would be), but the decision
+        comes from the reducer's shared generator, so every rank drops the same modality and FusedAdam skips the same
+        sub-modules everywhere, however each rank seeded `random` (ddp.GradReducer.broadcast_state)."""
+        modality = self.apply_teacher_forcing_modality()
+        rng = getattr(self._reducer, "shared_rng", None)
+        if rng is not None:
+            modality = ("image" if rng.random() < 0.5 else "audio") if rng.random() < self.teacher_forcing_modality_prob else "both"
+        return modality
 
     def training_step(self, batch, batch_idx) -> torch.Tensor:
         xi, xli, xa, xla, y_in, y_out = batch

@@ -136,7 +136,9 @@ class FusedAdam:
     set_to_none): no update from stale momentum, no moment decay, no step count.  In MultimodalTransformer the modality-drop
     steps (model.py:510-519) leave one encoder and cross_attn without gradients; the model reports the sub-modules that took
     part in the step through `touched_fn` and each sub-module keeps its own step count for the bias correction.  (Under data
-    parallelism every rank takes the same branch -- same Python `random` stream -- so all ranks skip the same slices.)"""
+    parallelism every rank takes the same branch BY CONSTRUCTION: the modality decision is drawn from a generator all ranks
+    seed with rank 0's value -- model.MultimodalTransformer._draw_modality, ddp.GradReducer.broadcast_state -- so all ranks
+    skip the same slices; tests/test_ddp_cpu.py runs it with ranks seeded differently.)"""
 
     def __init__(self, flat: FlatParams, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, touched_fn=None):
         self.flat = flat
