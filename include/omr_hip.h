@@ -165,6 +165,11 @@ int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const float* bias, 
                     int stat_mode, double* stat_ws, int stat_slots, const void* stat_x, const float* stat_mean, const float* stat_rstd,
                     void* stream);
 int omr_conv3x3_weight_flip(int dtype, const void* w, void* wd, int COUT, int CIN, void* stream);
+/* The same re-layout for n convs in ONE launch (descs is a HOST array): the data-gradient weights of every 3x3 conv are
+ * refreshed once per optimizer step, behind omr_adam, so the backward pass (aten::convolution_backward of encoder.py:132-150)
+ * carries no re-layout launches. */
+typedef struct omr_flip_desc { const void* w; void* wd; int cout, cin; } omr_flip_desc;
+int omr_conv3x3_weight_flip_grouped(int dtype, int n, const omr_flip_desc* descs, void* stream);
 /* dw[COUT][3][3][CIN] (fp32) += dy^T * im2col(x);  db[COUT] (nullable, fp32) += column sums of dy (bias gradient) */
 int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, const float* in_mean, const float* in_rstd, int B, int H, int W,
                       int CIN, int COUT, int stride_h, int stride_w, int Ho, int Wo, void* stream);

@@ -785,7 +785,7 @@ static void choose_split(int B, int H, int T, int S, int causal, int* nsplit, in
     *nsplit = 1; *split_len = 0;
     if (causal || S <= 256) return;
     int want;
-    if (T <= 32) want = (S + 255) / 256;
+    if (T <= 32) { want = (S + 255) / 256; if (want > 64) want = 64; }      // the merge prologue of omr_decode_linear takes <= 64 splits
     else {
         const long blocks = (long)B * H * ((T + 127) / 128);
         want = (int)((512 + blocks - 1) / blocks);               // at least ~512 workgroups (2 per CU); more buys nothing: the

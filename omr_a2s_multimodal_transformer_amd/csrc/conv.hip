@@ -38,6 +38,22 @@ __global__ void weight_flip_kernel(const T* __restrict__ w, T* __restrict__ wd, 
     }
 }
 
+// The same for SEVERAL convs in one launch (blockIdx.y = conv): the flipped copies of all 3x3 weights of a model are refreshed
+// once per optimizer step, right behind omr_adam, instead of one launch in front of every data gradient of the backward pass.
+constexpr int FLIP_MAX = 32;
+struct FlipTable { const void* w[FLIP_MAX]; void* wd[FLIP_MAX]; int cout[FLIP_MAX]; int cin[FLIP_MAX]; };
+template <typename T>
+__global__ void weight_flip_grouped_kernel(FlipTable t) {
+    const int g = blockIdx.y, COUT = t.cout[g], CIN = t.cin[g];
+    const T* __restrict__ w = (const T*)t.w[g];
+    T* __restrict__ wd = (T*)t.wd[g];
+    const long total = (long)COUT * 9 * CIN;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int n = (int)(i % COUT); long q = i / COUT; int tapd = (int)(q % 9); int c = (int)(q / 9);
+        wd[i] = w[((long)n * 9 + (8 - tapd)) * CIN + c];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Weight gradient of the 3x3 conv.  Workgroup = 2x2 waves; wave (wn, wc) owns the 32 couts x 32 cins
 // block (n0 + 32 wn, c0 + 32 wc) for all nine taps (9 x 16 accumulator registers).  K = output pixels:
@@ -910,6 +926,26 @@ extern "C" int omr_conv3x3_weight_flip(int dtype, const void* w, void* wd, int C
     if (COUT <= 0 || CIN <= 0) return OMR_ERR_ARG;
     long total = (long)COUT * 9 * CIN;
     DISPATCH_T(dtype, hipLaunchKernelGGL((weight_flip_kernel<T>), ew_grid(total), 256, 0, (hipStream_t)stream, (const T*)w, (T*)wd, COUT, CIN));
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" int omr_conv3x3_weight_flip_grouped(int dtype, int n, const omr_flip_desc* descs, void* stream) {
+    if (n < 0 || (n && !descs)) return OMR_ERR_ARG;
+    for (int base = 0; base < n; base += FLIP_MAX) {
+        FlipTable t = {};
+        const int cnt = n - base < FLIP_MAX ? n - base : FLIP_MAX;
+        long most = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const omr_flip_desc& d = descs[base + i];
+            if (!d.w || !d.wd || d.cout <= 0 || d.cin <= 0) return OMR_ERR_ARG;
+            t.w[i] = d.w; t.wd[i] = d.wd; t.cout[i] = d.cout; t.cin[i] = d.cin;
+            const long total = (long)d.cout * 9 * d.cin;
+            if (total > most) most = total;
+        }
+        const dim3 grid((unsigned)((most + 255) / 256 < 64 ? (most + 255) / 256 : 64), (unsigned)cnt);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((weight_flip_grouped_kernel<T>), grid, 256, 0, (hipStream_t)stream, t));
+    }
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }

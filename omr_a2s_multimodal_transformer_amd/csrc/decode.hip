@@ -52,7 +52,9 @@ size_t carve(const omr_decode_desc& d, char* base, Ws* w) {
 // (row, column): chunks in ascending k, the 16 k-lanes combined by a fixed cross-lane tree.  blockIdx.y picks RM rows; nothing in a row's
 // arithmetic depends on M or on the other rows.
 constexpr int RM = 8, NOUT = 16, KL = 16, WCH = 8;      // rows per workgroup, columns per workgroup, k-lanes, prefetched weight chunks per thread
-constexpr int MAXSPLIT = 32, MAXHS = 256;                // key splits the merge prologue takes (256 keys each: S <= 8192); heads x splits
+constexpr int MAXSPLIT = 64, MAXHS = 512;                // key splits the merge prologue takes (attention.hip choose_split caps a decode
+                                                         // row at 64 splits of >= 256 keys: the reference's largest memory, 12 696 tokens,
+                                                         // is 50); heads x splits
 
 // Sum over the 16 k-lanes of a column (= one DPP row): four cross-lane adds, every lane ends with the total.  (The generic
 // __shfl_xor butterfly is ~7 instructions per step through the LDS crossbar.)
@@ -295,7 +297,8 @@ extern "C" int omr_decode_steps(const omr_decode_desc* dp, long* tokens, int t0,
     // three add + LayerNorm, the merge of the key-split attention) is folded into the loading of the NEXT linear's input rows
     // (omr_decode_linear prologues); the residual stream alternates between two buffers because the workgroup that stores a
     // freshly normalised row runs beside workgroups still reading the previous one.
-    if (!d.fp8 && (dm == 128 || dm == 256 || dm == 512) && d.ff <= 2048 && d.ff % (16 * (dt == OMR_BF16 ? 8 : 4)) == 0 && d.S <= 256 * MAXSPLIT && d.max_len <= 256 * MAXSPLIT) {
+    const int smax = d.S > d.max_len ? d.S : d.max_len, splits_max = (smax + 255) / 256 < MAXSPLIT ? (smax + 255) / 256 : MAXSPLIT;
+    if (!d.fp8 && (dm == 128 || dm == 256 || dm == 512) && d.ff <= 2048 && d.ff % (16 * (dt == OMR_BF16 ? 8 : 4)) == 0 && d.nhead * splits_max <= MAXHS) {
         const long* tok_in = tokens;
         for (int s = 0; s < n_steps; ++s) {
             const int t = t0 + s;

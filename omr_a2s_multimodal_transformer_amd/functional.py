@@ -88,7 +88,8 @@ class Conv3x3Fn(Function):
         WgradStream.run("conv", lambda: K.conv3x3_wgrad(x, g, weight.omr_grad, stride=stride, in_stats=stats, db=bias.omr_grad), x, g, *(stats or ()))
         dx = None
         if ctx.needs_input_grad[0]:
-            wd = K.conv3x3_weight_flip(wt(weight, x.dtype))
+            flat = getattr(weight, "omr_flat", None)        # re-laid once per optimizer step (params.FlatParams.refresh_flips)
+            wd = flat.flipped(weight, x.dtype) if flat is not None else K.conv3x3_weight_flip(wt(weight, x.dtype))
             H, W = x.shape[1], x.shape[2]
             if stats is None:
                 dx = K.conv3x3(g, wd, None, stride=(1, 1), dil=stride, out_hw=(H, W), out_mask=x if mask_input else None, mask_scale=in_scale)

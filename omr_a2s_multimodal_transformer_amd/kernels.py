@@ -450,6 +450,29 @@ def conv3x3_weight_flip(w_phys: Tensor) -> Tensor:
     return wd
 
 
+class _FlipDesc(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("wd", ctypes.c_void_p), ("cout", ctypes.c_int), ("cin", ctypes.c_int)]
+
+
+def conv3x3_weight_flip_table(pairs):
+    """Host table for conv3x3_weight_flip_grouped: pairs of (w_phys [COUT,3,3,CIN], wd [CIN,3,3,COUT]) in one dtype.  Built once
+    (the tensors are fixed views of the flat parameter buffers) and reused every optimizer step."""
+    arr = (_FlipDesc * len(pairs))()
+    dt = pairs[0][0].dtype
+    for q, (w, wd) in zip(arr, pairs):
+        require_cuda(w, wd)
+        COUT, _, _, CIN = w.shape
+        assert w.dtype == wd.dtype == dt and w.is_contiguous() and wd.is_contiguous() and tuple(wd.shape) == (CIN, 3, 3, COUT)
+        q.w, q.wd, q.cout, q.cin = w.data_ptr(), wd.data_ptr(), COUT, CIN
+    return dtype_code(dt), len(pairs), arr
+
+
+def conv3x3_weight_flip_grouped(table) -> None:
+    """All data-gradient weight re-layouts of a model in ONE launch (omr_conv3x3_weight_flip_grouped)."""
+    code, n, arr = table
+    lib().call("omr_conv3x3_weight_flip_grouped", code, n, ctypes.byref(arr), cur_stream())
+
+
 def conv3x3_wgrad(x: Tensor, dy: Tensor, dw_phys: Tensor, stride=(1, 1), in_stats=None, db: Optional[Tensor] = None) -> None:
     """dw_phys (fp32 [COUT,3,3,CIN], accumulated in place) += grad; db (fp32 [COUT]) += bias grad (same pass over dy)."""
     require_cuda(x, dy, dw_phys, db)

@@ -95,16 +95,54 @@ class FlatParams:
                 p.omr_grad = gphys
                 p.grad = glogical
                 p.omr_lowp = views(self.lowp)[0] if self.lowp is not None else None
+        # Data-gradient weights of the dense 3x3 convs ([CIN,3,3,COUT], taps mirrored: the transposed conv's operand) in the
+        # compute dtype: refreshed once per optimizer step by ONE launch (refresh_flips) instead of one re-layout launch in front
+        # of every data gradient of the backward pass.  A per-parameter (torch version, update count) stamp guards manual edits.
+        convs = [p for p in self.params if p.dim() == 4 and tuple(p.shape[2:]) == (3, 3) and p.shape[1] > 1]
+        self.flip = torch.empty(sum(p.numel() for p in convs), dtype=compute_dtype, device=device)
+        self.updates = 0                 # weight updates that bypass torch's version counter (omr_adam writes through raw pointers)
+        self._flip_table = None
+        self._flip_params = convs
+        pairs, off = [], 0
+        for p in convs:
+            cout, cin = p.shape[0], p.shape[1]
+            p.omr_flip = self.flip[off:off + p.numel()].view(cin, 3, 3, cout)
+            p.omr_flat = self
+            p.omr_flip_stamp = None
+            off += p.numel()
+            pairs.append((p.omr_phys if compute_dtype == torch.float32 else p.omr_lowp, p.omr_flip))
+        self._flip_pairs = pairs
         self.sync_lowp()
 
     def sync_lowp(self) -> None:
         """Refresh the bf16 compute copy from the fp32 masters (after load_state_dict / manual edits)."""
         if self.lowp is not None:
             K.cast(self.master, torch.bfloat16, out=self.lowp)
+        self.refresh_flips()
+
+    def refresh_flips(self) -> None:
+        """Re-lay the data-gradient weights of all dense 3x3 convs from the current compute weights (one launch)."""
+        if not self._flip_pairs or not self.master.is_cuda:
+            return
+        if self._flip_table is None:
+            self._flip_table = K.conv3x3_weight_flip_table(self._flip_pairs)
+        K.conv3x3_weight_flip_grouped(self._flip_table)
+        for p in self._flip_params:
+            p.omr_flip_stamp = (p._version, self.updates)
+
+    def flipped(self, p: nn.Parameter, dtype: torch.dtype) -> torch.Tensor:
+        """Data-gradient weights of conv parameter p.  Current by construction after FusedAdam.step / sync_lowp; an in-place
+        edit of the parameter through torch (copy_, a sub-module's load_state_dict) bumps its version counter and triggers a
+        refresh here.  (In bf16 mode such an edit needs sync_compute_weights() anyway: the forward reads the bf16 copy.)"""
+        if dtype != self.compute_dtype:
+            return K.conv3x3_weight_flip(p.omr_phys if dtype == torch.float32 else p.omr_lowp)
+        if p.omr_flip_stamp != (p._version, self.updates):
+            self.refresh_flips()
+        return p.omr_flip
 
     def zero_grad(self) -> None:
         from .runtime import WgradStream
-        WgradStream.join()
+        WgradStream.reset()         # also drops what a failed backward pass left collected
         self.grad.zero_()
 
     def slice_of(self, names: Iterable[str]) -> Tuple[int, int]:
@@ -179,6 +217,8 @@ class FusedAdam:
         for b, e, st in runs:
             K.adam_step(f.master[b:e], f.grad[b:e], f.exp_avg[b:e], f.exp_avg_sq[b:e], st, g["lr"], g["betas"], g["eps"], grad_scale,
                         p_lowp=None if f.lowp is None else f.lowp[b:e])
+        f.updates += 1
+        f.refresh_flips()           # the next backward pass finds its data-gradient weights ready
 
     def state_dict(self):
         return dict(step=self.step_count, steps=dict(self.steps), exp_avg=self.flat.exp_avg, exp_avg_sq=self.flat.exp_avg_sq, param_groups=[

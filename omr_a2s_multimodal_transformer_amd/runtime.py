@@ -174,6 +174,16 @@ class WgradStream:
         cls._release_finished(everything=True)      # the main stream is ordered behind every side-stream read now
 
 
+    @classmethod
+    def reset(cls) -> None:
+        """Start of a step (FlatParams.zero_grad): nothing collected may survive into it.  After a backward pass that RAISED
+        (an OOM, GradReducer's second-backward error) the engine never ran the queued join(): `_callback` would stay set --
+        so the next pass would not queue its own join -- and the stale collected problems would be launched into the fresh
+        gradient buffer.  Drop them unlaunched, then order the streams like join()."""
+        cls._deferred = []
+        cls.join()
+
+
 class FlatModuleMixin:
     """Adds flat-buffer parameter storage (params.py) to a top-level nn.Module."""
 

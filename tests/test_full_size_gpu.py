@@ -1,5 +1,5 @@
-"""Parity at BASELINE.json's full sizes, where the CPU oracle is too slow to be the checker: size-independent properties of
-the reference's math instead.  What is run (stated per test):
+"""Size-independent properties of the reference's math at BASELINE.json's full sizes (the direct comparison with the CPU oracle at
+these shapes is tests/test_headline_parity_gpu.py: the oracle takes a few seconds there at batch 1-2).  What is run (stated per test):
 
   C2  image model: 256x2048 image (S = 4096 memory tokens), T = 512, **6 layers**, d_model 256, V = 6997 -- the benchmark's
       model exactly; batch 2-3 instead of 32 (every op on the path is per-sample, so the batch size only repeats the work).

@@ -27,6 +27,17 @@ def load(module, shapes, seed):
     return sd
 
 
+def check_grad_heads(model, names, ref_norms, ref_heads):
+    """The first 8 elements of every gradient tensor (logical layout) against the reference's own (F13 `*_grad_heads`), with the
+    criterion the oracle is held to (tests/test_oracle_golden_r2.py check_grads): single elements move more than norms."""
+    ps = dict(model.named_parameters())
+    heads = np.stack([np.pad(ps[n].grad.detach().float().flatten()[:8].cpu().numpy(), (0, max(0, 8 - ps[n].numel()))) for n in names])
+    ref_norms = np.where(np.asarray(ref_norms) < 0, 0.0, ref_norms)
+    rms = np.array([ref_norms[i] / np.sqrt(ps[n].numel()) for i, n in enumerate(names)])[:, None]
+    bad = np.abs(heads - ref_heads) > 5e-2 * np.abs(ref_heads) + 0.1 * rms + 1e-12
+    assert not bad.any(), [names[i] for i in np.flatnonzero(bad.any(axis=1))]
+
+
 def check_grad_norms(model, names, ref):
     """Norms against the reference's: hard 1e-2 on every tensor, 1e-3 on the typical one (single ReLU-mask flips between two
     fp32 implementations move whole tensors by ~1/sqrt(N): tests/test_dropout_parity_gpu.py has the measurement)."""
@@ -58,6 +69,7 @@ def test_unimodal_forward_backward_matches_reference_golden_nondegenerate(golden
     np.testing.assert_allclose(float(loss), float(g["uni_loss"]), rtol=1e-4)
     loss.backward()
     check_grad_norms(m, [str(n) for n in g["uni_grad_names"]], g["uni_grad_norms"])
+    check_grad_heads(m, [str(n) for n in g["uni_grad_names"]], g["uni_grad_norms"], g["uni_grad_heads"])
 
 
 @pytest.mark.parametrize("mt,modality", [("concat", "both"), ("attn_img", "both"), ("attn_audio", "both"), ("attn_both", "both"),
@@ -81,6 +93,7 @@ def test_multimodal_matches_reference_golden_nondegenerate(golden, mt, modality)
     np.testing.assert_allclose(float(loss), float(g[f"{mt}_{modality}_loss"]), rtol=1e-4)
     loss.backward()
     check_grad_norms(m, [str(n) for n in g[f"{mt}_{modality}_grad_names"]], g[f"{mt}_{modality}_grad_norms"])
+    check_grad_heads(m, [str(n) for n in g[f"{mt}_{modality}_grad_names"]], g[f"{mt}_{modality}_grad_norms"], g[f"{mt}_{modality}_grad_heads"])
     assert m._touched == {"both": None, "image": ("image_encoder", "decoder"), "audio": ("audio_encoder", "decoder")}[modality]
 
 
