@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--dtype", default="", choices=["", "bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-side-stream", action="store_true",
+                    help="profiling aid: weight gradients on the main stream (kernel durations in a trace are then not stretched by overlap)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="rehearse the multi-rank launch on the CPU: gloo group, no GPU work, prints the JSON contract with value 0")
     args = ap.parse_args()
@@ -125,6 +127,9 @@ def main():
         x1 = batch[0][:1]
     model.flatten_parameters(device=dev)
     model.train()
+    if args.no_side_stream:
+        from omr_a2s_multimodal_transformer_amd.runtime import WgradStream
+        WgradStream.enabled = False
     seed_dropout(1234, rank)
     reducer = model.attach_reducer() if world > 1 else None
     opt = model.configure_optimizers()

@@ -186,7 +186,17 @@ int omr_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, flo
  * reproduce CrossAttention.create_attention_mask incl. its (b*H+h)%B tiling (model.py:343-354). */
 int omr_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                  long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
-                 const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed, void* stream);
+                 const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed,
+                 const unsigned long long* drop_words, void* stream);
+/* Attention-probability dropout (nn.MultiheadAttention dropout, decoder.py:91; model.py:292-297).  The keep bits are a pure
+ * function of (seed, b, h, query, key).  With dropout_p > 0 the attention kernels do not hash: they READ the bits, 1 per score,
+ * from `drop_words` -- omr_attn_dropout_words_count(B, H, T, S) 64-bit words that omr_attn_dropout_words fills for
+ * (dropout_p, seed), once per (layer, step), in the accumulator layout of the kernels (word = one register of a 32-query x
+ * 64-key tile, bit = lane): forward and dQ take a word as the SGPR mask of one v_cndmask per score, dK/dV reads a 32-bit
+ * column of the same words per key.  Forward and backward of a layer get the same buffer.  drop_words may be NULL when
+ * dropout_p == 0. */
+long omr_attn_dropout_words_count(int B, int H, int T, int S);
+int omr_attn_dropout_words(unsigned long long* words, int B, int H, int T, int S, float dropout_p, unsigned long long seed, void* stream);
 /* omr_attn_fwd / omr_attn_bwd with caller-provided scratch that lets the library split the KEYS of a (batch, head, query block)
  * over several workgroups where that fills the chip better (the query-per-lane kernels have B*H*T/32 waves whatever S is:
  * 2 per SIMD at B 32, T 512): partial softmaxes / partial dQ sums are merged by fixed-order kernels, results are
@@ -195,13 +205,13 @@ int omr_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o
 long omr_attn_workspace_floats(int B, int H, int T, int S, int head_dim, int causal, int backward);
 int omr_attn_fwd_ws(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                     long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
-                    const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed, float* ws,
-                    long ws_floats, void* stream);
+                    const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed,
+                    const unsigned long long* drop_words, float* ws, long ws_floats, void* stream);
 int omr_attn_bwd_ws(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta_ws,
                     void* dq, void* dk, void* dv, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, long bsq,
                     long bsk, long bsv, long bso, long bsdo, long bsdq, long bsdk, long bsdv, int B, int H, int T, int S, int head_dim,
                     int causal, int window, const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p,
-                    unsigned long long seed, float* ws, long ws_floats, void* stream);
+                    unsigned long long seed, const unsigned long long* drop_words, float* ws, long ws_floats, void* stream);
 /* omr_attn_fwd for ONE block of at most 32 query rows (KV-cached decode: T = 1) with the keys split over workgroups of 256 keys
  * (partial softmaxes merged by a second small kernel): a single query row would otherwise keep each (batch, head) on one
  * workgroup walking all S keys.  No causal / block masks (a decode step sees every cached key), no dropout.
@@ -216,15 +226,15 @@ int omr_attn_fwd_split(int dtype, const void* q, const void* k, const void* v, v
 int omr_attn_fwd_split_partials(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv,
                                 long ldo, long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, float* split_ws,
                                 long split_ws_floats, int* nsplit, void* stream);
-/* Test / debug entry: the attention-probability dropout keep-mask (1 = kept) that omr_attn_fwd / omr_attn_bwd regenerate on
- * the fly for (seed, dropout_p), one byte per score, mask[B][H][T][S].  Lets a checker inject the very same mask into a CPU
+/* Test / debug entry: the attention-probability dropout keep-mask (1 = kept) for (seed, dropout_p) -- the function
+ * omr_attn_dropout_words packs -- one byte per score, mask[B][H][T][S].  Lets a checker inject the very same mask into a CPU
  * restatement of nn.MultiheadAttention's dropout (tests/test_dropout_parity_gpu.py). */
 int omr_attn_dropout_mask(unsigned char* mask, int B, int H, int T, int S, float dropout_p, unsigned long long seed, void* stream);
 int omr_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta_ws,
                  void* dq, void* dk, void* dv, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, long bsq,
                  long bsk, long bsv, long bso, long bsdo, long bsdq, long bsdk, long bsdv, int B, int H, int T, int S, int head_dim,
                  int causal, int window, const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p,
-                 unsigned long long seed, void* stream);
+                 unsigned long long seed, const unsigned long long* drop_words, void* stream);
 
 /* ---- KV-cached greedy decoding: one host call per run of tokens ------------------------------------------------------ */
 /* Reference: the autoregressive loop of Transformer.validation_step / get_pred_seq_and_pred_prob_seq (model.py:182-193,

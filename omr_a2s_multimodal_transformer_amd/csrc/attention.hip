@@ -28,6 +28,8 @@ struct AttnArgs {
     const int* blk_lq; const int* blk_lkv;             // [B] or null
     int B, H, T, S; float scale; int causal; int window;
     uint32_t drop_thresh; float drop_scale; uint64_t seed;
+    const uint64_t* dmask;                             // dropout keep bits (attn_dropout_words_kernel); passed to the kernels as a
+                                                       // separate __restrict__ parameter so that its loads become scalar loads
     // single-query-block forward split over the keys (decode): blockIdx.x = split, partials [B][H][nsplit][T][HD + 2] floats
     int nsplit, split_len; float* part;
     // backward only
@@ -115,20 +117,34 @@ template <typename T, int HD, int NR> struct RowTile {
     }
 };
 
-__device__ __forceinline__ bool attn_visible(const AttnArgs& a, int q, int key, int lq, int lkv) {
-    if (key >= a.S || q >= a.T) return false;
+// Visibility (length limits, causal / window band, CrossAttention's block mask) as a per-lane RANGE, computed once per kernel:
+// the keys a query row sees are [lo, lo + span) (lane = query: forward, dQ); the queries that see a key are such a range too
+// (lane = key: dK/dV).  A boundary tile then tests  (unsigned)(index - lo) < span  per score: no branches.
+__device__ __forceinline__ void visible_keys(const AttnArgs& a, int q, int lq, int lkv, int& lo, unsigned& span) {
+    int hi = q < a.T ? a.S : 0;
+    lo = 0;
     if (a.causal) {
-        if (key > q) return false;
-        if (a.window > 0 && a.window < a.T && key < q - a.window) return false;
+        hi = min(hi, q + 1);
+        if (a.window > 0 && a.window < a.T) lo = max(0, q - a.window);
     }
-    if (lq >= 0 && q >= lq && key >= lkv) return false;
-    return true;
+    if (lq >= 0 && q >= lq) hi = min(hi, lkv);
+    span = (unsigned)max(hi - lo, 0);
 }
-// Attention-probability dropout mask (nn.MultiheadAttention dropout, decoder.py:91).  The softmax kernels are VALU-bound
-// (hd = 64: ~20 vector ops per score against 2 MFMA issue slots), so the mask is as cheap as it gets: ONE 7-op
-// multiply-xorshift hash of the pair index (q, key >> 1), keyed per (seed, b, h), decides two adjacent keys with 16 bits
-// each (keep iff bits >= p * 2^16).  Forward and both backward kernels regenerate exactly the same mask; nothing is
-// stored.  The 1/(1-p) rescale is folded out of the per-score code (applied to O / dV / inside an fma).
+__device__ __forceinline__ void visible_queries(const AttnArgs& a, int key, int lq, int lkv, int& lo, unsigned& span) {
+    int hi = key < a.S ? a.T : 0;
+    lo = 0;
+    if (a.causal) {
+        lo = key;
+        if (a.window > 0 && a.window < a.T) hi = min(hi, key + a.window + 1);
+    }
+    if (lq >= 0 && key >= lkv) hi = min(hi, lq);
+    span = (unsigned)max(hi - lo, 0);
+}
+// Attention-probability dropout mask (nn.MultiheadAttention dropout, decoder.py:91): ONE 7-op multiply-xorshift hash of the
+// pair index (q, key >> 1), keyed per (seed, b, h), decides two adjacent keys with 16 bits each (keep iff bits >= p * 2^16).
+// The bits are a pure function of (seed, b, h, q, key); attn_dropout_words_kernel evaluates it once per (layer, step) into
+// the word layout the three kernels consume (1 bit per score).  The 1/(1-p) rescale is folded out of the per-score code
+// (applied to O / dV / dQ / dK).
 __device__ __forceinline__ uint32_t attn_bh_key(const AttnArgs& a, int b, int h) {
     return hash32((uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)(b * a.H + h));
 }
@@ -143,50 +159,128 @@ __device__ __forceinline__ bool attn_keep_lo(uint32_t x, uint32_t thr32) { retur
 __device__ __forceinline__ bool attn_keep_hi(uint32_t x, uint32_t thr32) { return x >= thr32; }
 
 // ------------------------------------------------------------------------------------------------
+// Vector-instruction budget.  The kernels below are bound by the VALU issue rate, not by the matrix pipe (hd = 64: a lane owns 2
+// scores per MFMA), so everything that can leave the per-score vector code does:
+//   * the softmax scale * log2(e) is folded into the Q (forward, dQ) / K (dK, dV) fragments once per kernel;
+//   * the additive terms of a score -- key bias, minus the row's reference maximum (forward) or log-sum-exp (backward), minus
+//     delta / c for dP -- ride on ONE extra k-step of the score's MFMA chain ("augmented k-step"): side X carries a value in
+//     two bf16 slots (hi + lo = the fp32 value to 2^-17; fp32 mode: one exact slot) against unit slots of side Y and vice versa,
+//     so the accumulator leaves the chain as  s * scale * log2 e + bias - reference  and the only vector work on a score is the exp2;
+//   * forward: the reference maximum is LAGGED (it moves only when a tile's maximum exceeds it by more than 2^THR, a
+//     wave-uniform rare branch), so no subtraction and no accumulator rescale in the common tile;
+//   * attention-probability dropout: the keep bits are generated ONCE per (layer, step) by attn_dropout_words_kernel in the
+//     accumulator's own lane layout -- one 64-bit word per (32 queries, register) -- and the kernels apply them with one
+//     v_cndmask per score whose mask operand is that word in an SGPR pair (forward, dQ: scalar loads) or, in the key-per-lane
+//     dK/dV kernel, from the same words read as one 32-bit column per lane (v_bfe + v_and / v_bfi).
+template <typename T> struct Aug;
+template <> struct Aug<bf16> {
+    static __device__ __forceinline__ void split(float v, bf16& hi, bf16& lo) {
+        hi = (bf16)v;
+        const float r = v - (float)hi;
+        lo = (r == r) ? (bf16)r : (bf16)0.f;                  // v = +-inf: hi carries it, inf - inf = NaN is dropped
+    }
+    static __device__ __forceinline__ bf16x8 x(float v) {
+        bf16 hi, lo; split(v, hi, lo);
+        const bf16 one = (bf16)1.f, z = (bf16)0.f;
+        const bf16x8 f = {hi, lo, one, one, z, z, z, z};
+        return f;
+    }
+    static __device__ __forceinline__ bf16x8 y(float v) {
+        bf16 hi, lo; split(v, hi, lo);
+        const bf16 one = (bf16)1.f, z = (bf16)0.f;
+        const bf16x8 f = {one, one, hi, lo, z, z, z, z};
+        return f;
+    }
+};
+template <> struct Aug<float> {
+    static __device__ __forceinline__ f32x4 x(float v) { const f32x4 f = {v, 1.f, 0.f, 0.f}; return f; }
+    static __device__ __forceinline__ f32x4 y(float v) { const f32x4 f = {1.f, v, 0.f, 0.f}; return f; }
+};
+// x . y over the augmented k-step = x's value + y's value; only the lanes of the lower k half (lane < 32) carry the slots.
+
+// Both halves of the wave (lanes i and i + 32 hold the two k-halves of one row): v_permlane32_swap instead of a ds_bpermute
+// shuffle -- an LDS-pipe instruction would make the kernel wait on lgkmcnt, i.e. on the scalar dropout-word loads in flight.
+__device__ __forceinline__ float max_halves(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const unsigned lo = r[0], hi = r[1];                        // the lower half's value / the upper half's value, in every lane
+    return fmaxf(__uint_as_float(lo), __uint_as_float(hi));
+}
+
+// One score under its dropout bit: mask = the 64-bit word of this accumulator register (bit = lane)
+__device__ __forceinline__ float keep_or_zero(float x, uint64_t mask) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ float keep_or(float x, float alt, uint64_t mask) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(alt), "v"(x), "s"(mask));
+    return r;
+}
+// Dropout words: [B*H][ceil(T/32)][ceil(S/64)][32] 64-bit words; word (mb, r) of a (32-query, 64-key) tile holds, at bit
+// (query & 31) + 32 * hh, the keep bit of key  tile*64 + mb*32 + acc_row(r, hh).
+// (indices are clamped to the last block: waves whose rows lie beyond T / S read valid words and discard the result)
+__device__ __forceinline__ long drop_word_base(const AttnArgs& a, int bh, int qb32, int kt) {
+    const int nqb = (a.T + 31) >> 5, nkt = (a.S + 63) >> 6;
+    return (((long)bh * nqb + min(qb32, nqb - 1)) * nkt + min(kt, nkt - 1)) * 32;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Forward.  grid = (ceil(T/128), H, B); wave w owns query rows q0 + 32w .. +31; KV tiles of 64 keys.
 // SPLITW (T <= 32: KV-cached greedy decode, one query row): the four waves would own the same 32 rows, so they split the KEYS
 // instead -- 256 keys are staged per step, wave w takes keys [64w, 64w+64) of them -- and their (max, sum, O) partials are
 // merged through LDS at the end.  Same arithmetic per score, a quarter of the serial tile walk.
-template <typename T, int HD, bool SPLITW>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+template <typename T, int HD, bool SPLITW, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a, const uint64_t* __restrict__ dmask) {
     typedef typename Frag<T>::type F;
     constexpr int VEC = ACfg<T>::VEC, NFR = ACfg<T>::NFR, KS = KStep<T>::value;
     constexpr int NKS = HD / KS, NDB = HD / 32, BKV = 64;
     constexpr int NTL = SPLITW ? 4 : 1, BST = BKV * NTL;        // keys staged per step
     constexpr int PK = HD + VEC;          // Ks pitch
     constexpr int PV = BST + 4;   // Vt pitch: 136 B (bf16) / 272 B (fp32) -> conflict-free permuted reads
+    constexpr float THR = 8.f;            // the reference maximum of a row moves when a tile exceeds it by 2^THR
     __shared__ __attribute__((aligned(16))) T Ks[BST * PK];
     constexpr bool TRD = std::is_same<T, bf16>::value;          // bf16: V is staged row-major and read with tr reads
     __shared__ __attribute__((aligned(16))) T Vt[TRD ? 8 : HD * PV];
     __shared__ __attribute__((aligned(16))) T Vs[TRD ? BST * PK : 8];
-    __shared__ __attribute__((aligned(16))) float bias_s[BST];
+    __shared__ __attribute__((aligned(16))) F Ka[BST + 1];      // augmented k-step, key side: the key bias; entry BST = zeros
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // blockIdx.x = key split (SPLITW: one query block) or query block + nqb * key split
     const int nqb = SPLITW ? 1 : (a.T + 127) / 128;
     const int ksplit = blockIdx.x / nqb, q0 = (blockIdx.x % nqb) * 128;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q = q0 + (SPLITW ? 0 : wave * 32) + (lane & 31);
+    const int qw0 = q0 + (SPLITW ? 0 : wave * 32);              // first query row of this wave
+    const int q = qw0 + (lane & 31);
     const int kboff = SPLITW ? wave * BKV : 0;                  // this wave's keys inside the staged block
     const T* Q = (const T*)a.q + (long)b * a.bsq + h * HD;
     const T* K = (const T*)a.k + (long)b * a.bsk + h * HD;
     const T* V = (const T*)a.v + (long)b * a.bsv + h * HD;
 
-    F qf[NKS];
+    const float sc2 = a.scale * LOG2E;
+    F qf[NKS];                                                  // Q * scale * log2 e
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-        qf[ks] = q < a.T ? *reinterpret_cast<const F*>(Q + (long)q * a.ldq + ks * KS + hh * VEC) : frag_zero<T>();
+    for (int ks = 0; ks < NKS; ++ks) {
+        const F raw = q < a.T ? *reinterpret_cast<const F*>(Q + (long)q * a.ldq + ks * KS + hh * VEC) : frag_zero<T>();
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) qf[ks][e] = from_f32<T>(to_f32(raw[e]) * sc2);
+    }
     int lq = -1, lkv = 0;
     if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
-    const uint32_t bh_key = attn_bh_key(a, b, h), s2 = (uint32_t)(a.S + 1) >> 1, thr32 = a.drop_thresh << 16;
+    int vis_lo; unsigned vis_span;
+    visible_keys(a, q, lq, lkv, vis_lo, vis_span);
 
     f32x16 acc_o[NDB];
 #pragma unroll
     for (int d = 0; d < NDB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const float sc2 = a.scale * LOG2E;
+    // m_ref: the row's reference maximum (log2 domain; exactly representable in T, so that one slot of the augmented k-step
+    // subtracts it without rounding); meaningless until m_set
+    float m_ref = 0.f, l_run = 0.f;
+    bool m_set = false;
+    F qa = hh ? frag_zero<T>() : Aug<T>::y(0.f);
     const bool win_on = a.window > 0 && a.window < a.T;
 
     int kv_beg = 0, kv_end = a.S;
@@ -202,17 +296,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         vt.load(V, a.ldv, kvb, a.S, tid);
         if (tid < BST) bias_r = (a.key_bias && kvb + tid < a.S) ? a.key_bias[(long)b * a.S + kvb + tid] * LOG2E : 0.f;
     };
+    if (tid == 0) Ka[BST] = frag_zero<T>();
     if (kv_beg < kv_end) prefetch(kv_beg);
     for (int kvb = kv_beg; kvb < kv_end; kvb += BST) {
         __syncthreads();
         kt.template store<PK>(Ks, tid);
         if constexpr (TRD) vt.template store<PK>(Vs, tid);
         else vt.template store_t<PV>(Vt, tid);
-        if (tid < BST) bias_s[tid] = bias_r;
+        if (tid < BST) Ka[tid] = Aug<T>::x(bias_r);
         __syncthreads();
         if (kvb + BST < kv_end) prefetch(kvb + BST);
         const int kv0 = kvb + kboff;                            // first key of this wave's 64-key tile
+        const uint64_t* wp = DROP ? dmask + drop_word_base(a, b * a.H + h, qw0 >> 5, min(kv0, a.S - 1) >> 6) : nullptr;
 
+        // scores in the log2 domain, already relative to the row's reference:  s * scale * log2 e + bias - m_ref
         f32x16 st[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
@@ -223,72 +320,66 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 const F kf = *reinterpret_cast<const F*>(&Ks[(kboff + mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
                 mma32(st[mb], kf, qf[ks]);
             }
+            mma32(st[mb], Ka[hh ? BST : kboff + mb * 32 + (lane & 31)], qa);
         }
-        // scores -> log2-domain logits (scale and bias pre-multiplied by log2 e), running max.  Tiles that are entirely
-        // visible for this wave's 32 query rows (the common case) skip every per-element mask test.
-        const int qw0 = q0 + (SPLITW ? 0 : wave * 32);
+        // The tile's dropout words are requested HERE: scalar loads share lgkmcnt with the LDS reads and return out of order, so
+        // the next wait on an LDS operand also waits for them -- behind the score chain the next LDS read is the first V
+        // fragment, a whole softmax (~450 issue cycles) away, and the words land under the max / exp2 / sum code.
+        uint64_t w0[16], w1[16];
+        if constexpr (DROP) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { w0[r] = wp[r]; w1[r] = wp[16 + r]; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // Tiles that are entirely visible for this wave's 32 query rows (the common case) skip every per-element mask test.
         const bool full = (kv0 + BKV <= a.S) && (qw0 + 32 <= a.T) && lq < 0 &&
                           (!a.causal || (kv0 + BKV - 1 <= qw0 && (!win_on || kv0 >= qw0 + 31 - a.window)));
-        float mx = -INFINITY;
-        if (full) {          // wave-uniform: the unmasked tile never evaluates a visibility test
+        if (!full) {
+            const int rel = kv0 + 4 * hh - vis_lo;
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 bz = *reinterpret_cast<const f32x4*>(&bias_s[kboff + mb * 32 + 8 * g + 4 * hh]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float sv = fmaf(st[mb][4 * g + e], sc2, bz[e]);
-                        st[mb][4 * g + e] = sv;
-                        mx = fmaxf(mx, sv);
-                    }
-                }
-        } else {
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 bz = *reinterpret_cast<const f32x4*>(&bias_s[kboff + mb * 32 + 8 * g + 4 * hh]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float sv = fmaf(st[mb][4 * g + e], sc2, bz[e]);
-                        if (!attn_visible(a, q, kv0 + mb * 32 + 8 * g + 4 * hh + e, lq, lkv)) sv = -INFINITY;
-                        st[mb][4 * g + e] = sv;
-                        mx = fmaxf(mx, sv);
-                    }
-                }
+                for (int r = 0; r < 16; ++r)
+                    st[mb][r] = (unsigned)(rel + mb * 32 + acc_row(r, 0)) < vis_span ? st[mb][r] : -INFINITY;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_use);
+        float mx = fmaxf(st[0][0], st[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, st[0][r]), st[1][r]);
+        mx = max_halves(mx);
+        const bool fix = m_set ? (mx > THR) : (mx > -INFINITY);   // the same for both lanes of a row
+        if (__builtin_amdgcn_ballot_w64(fix) != 0) {              // rare: first tile of a row, or its maximum grew past the threshold
+            const float m2 = fix ? to_f32(from_f32<T>(m_ref + mx)) : m_ref;
+            const float delta = m2 - m_ref;
+            const float alpha = (fix && m_set) ? __builtin_amdgcn_exp2f(-delta) : 1.f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[mb][r] -= delta;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+            m_ref = m2;
+            m_set = m_set || fix;
+            qa = hh ? frag_zero<T>() : Aug<T>::y(-m_ref);
+        }
         float psum = 0.f;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(st[mb][r] - m_use);   // exp2(-inf) = 0 for masked keys
+                const float pv = __builtin_amdgcn_exp2f(st[mb][r]);          // exp2(-inf) = 0 for masked keys
                 psum += pv;
                 st[mb][r] = pv;
             }
-        if (a.drop_thresh != 0) {      // registers 2j, 2j+1 of a block are adjacent keys: one hash per pair
-            const uint32_t pbase = (uint32_t)q * s2 + (uint32_t)((kv0 + 4 * hh) >> 1);
+        l_run += psum;
+        if constexpr (DROP) {
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+            for (int r = 0; r < 16; ++r) st[0][r] = keep_or_zero(st[0][r], w0[r]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t x = attn_rand2(bh_key, pbase + (uint32_t)((mb * 32 + acc_row(2 * j, 0)) >> 1));
-                    st[mb][2 * j] = attn_keep_lo(x, thr32) ? st[mb][2 * j] : 0.f;
-                    st[mb][2 * j + 1] = attn_keep_hi(x, thr32) ? st[mb][2 * j + 1] : 0.f;
-                }
-        }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-        if (!__all(alpha == 1.f)) {      // the running max moved for some row of this wave: rescale the O accumulators
-#pragma unroll
-            for (int d = 0; d < NDB; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+            for (int r = 0; r < 16; ++r) st[1][r] = keep_or_zero(st[1][r], w1[r]);
         }
         // O^T += V^T . P^T
 #pragma unroll
@@ -304,6 +395,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             }
     }
     float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float m_fin = l_tot > 0.f ? m_ref : -INFINITY;              // a row that saw no finite score has no reference
     if constexpr (SPLITW) {
         // merge the four waves' partial softmaxes of the same 32 query rows (log2 domain): the staging tiles are dead
         __syncthreads();
@@ -316,7 +408,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o_s[(wave * HD + d * 32 + acc_row(r, lane)) * 32 + qi] = acc_o[d][r];
-        if (hh == 0) { m_s[wave * 32 + qi] = m_run; l_s[wave * 32 + qi] = l_tot; }
+        if (hh == 0) { m_s[wave * 32 + qi] = m_fin; l_s[wave * 32 + qi] = l_tot; }
         __syncthreads();
         if (wave != 0) return;
         float mm = -INFINITY;
@@ -330,7 +422,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             wsc[w] = mw == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw - mm);
             l_tot += l_s[w * 32 + qi] * wsc[w];
         }
-        m_run = mm;
+        m_fin = mm;
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -341,14 +433,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 acc_o[d][r] = v;
             }
     }
-    if (a.nsplit > 1) {          // partial softmax of this key split: un-normalised O, running max (log2 domain) and sum
+    if (a.nsplit > 1) {          // partial softmax of this key split: un-normalised O, reference maximum (log2 domain) and sum
         if (q < a.T) {
             float* P = a.part + ((((long)b * a.H + h) * a.nsplit + ksplit) * a.T + q) * (HD + 2);
 #pragma unroll
             for (int d = 0; d < NDB; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) P[d * 32 + acc_row(r, lane)] = acc_o[d][r];
-            if (hh == 0) { P[HD] = m_run; P[HD + 1] = l_tot; }
+            if (hh == 0) { P[HD] = m_fin; P[HD + 1] = l_tot; }
         }
         return;
     }
@@ -359,7 +451,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[d * 32 + acc_row(r, lane)] = from_f32<T>(acc_o[d][r] * inv);
-        if (hh == 0 && a.lse) a.lse[((long)b * a.H + h) * a.T + q] = (l_tot > 0.f) ? (m_run + log2f(l_tot)) * LN2 : -INFINITY;
+        if (hh == 0 && a.lse) a.lse[((long)b * a.H + h) * a.T + q] = (l_tot > 0.f) ? (m_fin + log2f(l_tot)) * LN2 : -INFINITY;
     }
 }
 
@@ -400,10 +492,11 @@ __global__ void attn_delta_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward, dQ.  Same orientation as the forward: lane = query row.
-//   S^T = K Q^T ; P^T = exp(S^T - lse) ; dP^T = V dO^T ; dS^T = P^T o (M o dP^T - delta) ; dQ^T += K^T dS^T
-template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+// Backward, dQ.  Same orientation as the forward: lane = query row.  c = 1 / (1 - p_drop), M = keep mask:
+//   S'^T = K Q~^T + bias - lse  (augmented k-step) ; P^T = exp2(S'^T) ; dP'^T = V dO^T - delta / c  (augmented k-step)
+//   dS^T / c = P^T o (M ? dP'^T : -delta / c) ; dQ^T += K^T dS^T / c ; dQ = scale * c * dQ^T
+template <typename T, int HD, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a, const uint64_t* __restrict__ dmask) {
     typedef typename Frag<T>::type F;
     constexpr int VEC = ACfg<T>::VEC, NFR = ACfg<T>::NFR, KS = KStep<T>::value;
     constexpr int NKS = HD / KS, NDB = HD / 32, BKV = 64;
@@ -413,33 +506,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) T Vs[BKV * PK];
     constexpr bool TRD = std::is_same<T, bf16>::value;          // bf16: K^T fragments are tr reads of the row-major Ks tile
     __shared__ __attribute__((aligned(16))) T Kt[TRD ? 8 : HD * PV];
-    __shared__ __attribute__((aligned(16))) float bias_s[BKV];
+    __shared__ __attribute__((aligned(16))) F Ka[BKV + 1];      // augmented k-step, key side: the key bias; entry BKV = zeros
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nqb = (a.T + 127) / 128;                          // blockIdx.x = query block + nqb * key split
     const int ksplit = blockIdx.x / nqb, q0 = (blockIdx.x % nqb) * 128;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q = q0 + wave * 32 + (lane & 31);
+    const int qw0 = q0 + wave * 32;
+    const int q = qw0 + (lane & 31);
     const T* Q = (const T*)a.q + (long)b * a.bsq + h * HD;
     const T* K = (const T*)a.k + (long)b * a.bsk + h * HD;
     const T* V = (const T*)a.v + (long)b * a.bsv + h * HD;
     const T* DO = (const T*)a.dout + (long)b * a.bsdo + h * HD;
 
+    const float sc2 = a.scale * LOG2E;
     F qf[NKS], dof[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-        qf[ks] = q < a.T ? *reinterpret_cast<const F*>(Q + (long)q * a.ldq + ks * KS + hh * VEC) : frag_zero<T>();
+        const F raw = q < a.T ? *reinterpret_cast<const F*>(Q + (long)q * a.ldq + ks * KS + hh * VEC) : frag_zero<T>();
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) qf[ks][e] = from_f32<T>(to_f32(raw[e]) * sc2);
         dof[ks] = q < a.T ? *reinterpret_cast<const F*>(DO + (long)q * a.lddo + ks * KS + hh * VEC) : frag_zero<T>();
     }
     const long sidx = ((long)b * a.H + h) * a.T + q;
-    const float lse2 = q < a.T ? a.lse[sidx] * LOG2E : 0.f;
-    const float dl = q < a.T ? a.delta[sidx] : 0.f;
-    const float sc2 = a.scale * LOG2E;
-    const bool win_on = a.window > 0 && a.window < a.T, drop = a.drop_thresh != 0;
-    const int qw0 = q0 + wave * 32;
+    float lse2 = q < a.T ? a.lse[sidx] * LOG2E : 0.f;
+    if (!(lse2 > -INFINITY)) lse2 = 0.f;                        // a row without a visible key: every P is zeroed by its mask below
+    const float ndc = q < a.T ? -a.delta[sidx] / a.drop_scale : 0.f;      // -delta / c
+    const bool win_on = a.window > 0 && a.window < a.T;
     int lq = -1, lkv = 0;
     if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
-    const uint32_t bh_key = attn_bh_key(a, b, h), s2 = (uint32_t)(a.S + 1) >> 1, thr32 = a.drop_thresh << 16;
+    int vis_lo; unsigned vis_span;
+    visible_keys(a, q, lq, lkv, vis_lo, vis_span);
+    const F qa = hh ? frag_zero<T>() : Aug<T>::y(-lse2);        // query side of the score chain: minus the row's log-sum-exp
+    const F da = hh ? frag_zero<T>() : Aug<T>::y(ndc);          // dO side of the dP chain: minus delta / c
+    const F va = hh ? frag_zero<T>() : Aug<T>::x(0.f);          // V side of the dP chain: the unit slots
 
     f32x16 acc_q[NDB];
 #pragma unroll
@@ -460,55 +561,68 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         vt.load(V, a.ldv, kv0, a.S, tid);
         if (tid < BKV) bias_r = (a.key_bias && kv0 + tid < a.S) ? a.key_bias[(long)b * a.S + kv0 + tid] * LOG2E : 0.f;
     };
+    if (tid == 0) Ka[BKV] = frag_zero<T>();
     if (kv_beg < kv_end) prefetch(kv_beg);
     for (int kv0 = kv_beg; kv0 < kv_end; kv0 += BKV) {
         __syncthreads();
         kt.template store<PK>(Ks, tid);
         vt.template store<PK>(Vs, tid);
         if constexpr (!TRD) kt.template store_t<PV>(Kt, tid);
-        if (tid < BKV) bias_s[tid] = bias_r;
+        if (tid < BKV) Ka[tid] = Aug<T>::x(bias_r);
         __syncthreads();
         if (kv0 + BKV < kv_end) prefetch(kv0 + BKV);
         const bool full = (kv0 + BKV <= a.S) && (qw0 + 32 <= a.T) && lq < 0 &&
                           (!a.causal || (kv0 + BKV - 1 <= qw0 && (!win_on || kv0 >= qw0 + 31 - a.window)));
+        const uint64_t* wp = DROP ? dmask + drop_word_base(a, b * a.H + h, qw0 >> 5, kv0 >> 6) : nullptr;
+        f32x16 st[2], dp[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
-            f32x16 st, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { st[mb][r] = 0.f; dp[mb][r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const F kf = *reinterpret_cast<const F*>(&Ks[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
-                mma32(st, kf, qf[ks]);
+                mma32(st[mb], kf, qf[ks]);
                 const F vf = *reinterpret_cast<const F*>(&Vs[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
-                mma32(dp, vf, dof[ks]);
+                mma32(dp[mb], vf, dof[ks]);
             }
-            // P^T = exp2(score - lse) (0 where masked); wave-uniform branches keep the common tile free of mask / dropout tests
+            mma32(st[mb], Ka[hh ? BKV : mb * 32 + (lane & 31)], qa);
+            mma32(dp[mb], va, da);
+        }
+        // dropout words: requested behind the last LDS operand of the score / dP chains (see the forward kernel), consumed
+        // behind the 32 exp2
+        uint64_t w0[16], w1[16];
+        if constexpr (DROP) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bz = *reinterpret_cast<const f32x4*>(&bias_s[mb * 32 + 8 * g + 4 * hh]);
+            for (int r = 0; r < 16; ++r) { w0[r] = wp[r]; w1[r] = wp[16 + r]; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // P^T = exp2(score - lse) (0 where masked); wave-uniform branches keep the common tile free of mask tests
 #pragma unroll
-                for (int e = 0; e < 4; ++e) st[4 * g + e] = __builtin_amdgcn_exp2f(fmaf(st[4 * g + e], sc2, bz[e]) - lse2);
-            }
-            if (!full) {
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (!attn_visible(a, q, kv0 + mb * 32 + acc_row(r, lane), lq, lkv)) st[r] = 0.f;
-            }
-            if (drop) {
-                const uint32_t pbase = (uint32_t)q * s2 + (uint32_t)((kv0 + mb * 32 + 4 * hh) >> 1);
+            for (int r = 0; r < 16; ++r) st[mb][r] = __builtin_amdgcn_exp2f(st[mb][r]);
+        if (!full) {
+            const int rel = kv0 + 4 * hh - vis_lo;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t x = attn_rand2(bh_key, pbase + (uint32_t)(acc_row(2 * j, 0) >> 1));
-                    dp[2 * j] = attn_keep_lo(x, thr32) ? dp[2 * j] : 0.f;
-                    dp[2 * j + 1] = attn_keep_hi(x, thr32) ? dp[2 * j + 1] : 0.f;
-                }
-            }
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = st[r] * fmaf(dp[r], a.drop_scale, -dl);     // dS^T = P o (M o dP / (1-p) - delta)
+                for (int r = 0; r < 16; ++r) st[mb][r] = (unsigned)(rel + mb * 32 + acc_row(r, 0)) < vis_span ? st[mb][r] : 0.f;
+        }
+        if constexpr (DROP) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[0][r] = keep_or(dp[0][r], ndc, w0[r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[1][r] = keep_or(dp[1][r], ndc, w1[r]);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[mb][r] *= dp[mb][r];                 // dS^T / c
 #pragma unroll
             for (int s = 0; s < NFR; ++s) {
-                const F sf = acc_to_frag<T>(st, s);
+                const F sf = acc_to_frag<T>(st[mb], s);
 #pragma unroll
                 for (int d = 0; d < NDB; ++d) {
                     const F kf = kperm_frag<T>(Ks, PK, Kt, PV, mb * 32, s, d * 32, lane);
@@ -517,19 +631,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
             }
         }
     }
+    const float osc = a.scale * a.drop_scale;
     if (q < a.T) {
         if (a.nsplit > 1) {          // partial dQ of this key split, fp32 [nsplit][B][T][H*HD]: summed by attn_dq_sum_kernel
             float* PQ = a.part + ((((long)ksplit * a.B + b) * a.T + q) * a.H + h) * HD;
 #pragma unroll
             for (int d = 0; d < NDB; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) PQ[d * 32 + acc_row(r, lane)] = acc_q[d][r] * a.scale;
+                for (int r = 0; r < 16; ++r) PQ[d * 32 + acc_row(r, lane)] = acc_q[d][r] * osc;
         } else {
             T* DQ = (T*)a.dq + (long)b * a.bsdq + (long)q * a.lddq + h * HD;
 #pragma unroll
             for (int d = 0; d < NDB; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) DQ[d * 32 + acc_row(r, lane)] = from_f32<T>(acc_q[d][r] * a.scale);
+                for (int r = 0; r < 16; ++r) DQ[d * 32 + acc_row(r, lane)] = from_f32<T>(acc_q[d][r] * osc);
         }
     }
 }
@@ -548,10 +663,12 @@ __global__ void attn_dq_sum_kernel(AttnArgs a, int hd) {
 
 // ------------------------------------------------------------------------------------------------
 // Backward, dK and dV.  grid = (ceil(S/128), H, B); wave w owns keys k0 + 32w .. +31 (lane = key), queries
-// on the register axis:  S = Q K^T ; P = exp(S - lse) ; dP = dO V^T ; dS = P o (M o dP - delta)
-//   dV += (M o P)^T dO      dK += dS^T Q        (A operand straight from accumulator registers)
-template <typename T, int HD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+// on the register axis:  S' = Q K~^T + bias - lse ; P = exp2(S') ; dP' = dO V^T - delta / c  (both by augmented k-steps)
+//   dV += (M o P)^T dO      dK += (dS / c)^T Q,  dS / c = P o (M ? dP' : -delta / c)        (A operand straight from accumulator registers)
+// K~ = K * scale * log2 e is rounded to T here while the forward rounds Q * scale * log2 e: in bf16 the recomputed P differs from
+// the forward's by the two roundings (a few 1e-3 relative, the size of P's own bf16 rounding); exact in fp32.
+template <typename T, int HD, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a, const uint64_t* __restrict__ dmask) {
     typedef typename Frag<T>::type F;
     constexpr int VEC = ACfg<T>::VEC, NFR = ACfg<T>::NFR, KS = KStep<T>::value;
     constexpr int NKS = HD / KS, NDB = HD / 32, BQ = 64;
@@ -562,31 +679,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     constexpr bool TRD = std::is_same<T, bf16>::value;          // bf16: Q^T / dO^T fragments are tr reads of Qs / Ds
     __shared__ __attribute__((aligned(16))) T Qt[TRD ? 8 : HD * PT];
     __shared__ __attribute__((aligned(16))) T Dt[TRD ? 8 : HD * PT];
-    __shared__ __attribute__((aligned(16))) float lse_s[BQ];
-    __shared__ __attribute__((aligned(16))) float del_s[BQ];
+    __shared__ __attribute__((aligned(16))) F Qa[BQ + 1];       // augmented k-step, query side of the score chain: -lse; entry BQ = zeros
+    __shared__ __attribute__((aligned(16))) F Da[BQ + 1];       // ... of the dP chain: -delta / c
+    __shared__ __attribute__((aligned(16))) float ndc_s[BQ];    // -delta / c per query row (the value a dropped score takes)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 128;
-    const int key = k0 + wave * 32 + (lane & 31);
+    const int kw0 = k0 + wave * 32;
+    const int key = kw0 + (lane & 31);
     const T* Q = (const T*)a.q + (long)b * a.bsq + h * HD;
     const T* K = (const T*)a.k + (long)b * a.bsk + h * HD;
     const T* V = (const T*)a.v + (long)b * a.bsv + h * HD;
     const T* DO = (const T*)a.dout + (long)b * a.bsdo + h * HD;
 
+    const float sc2 = a.scale * LOG2E;
     F kf[NKS], vf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-        kf[ks] = key < a.S ? *reinterpret_cast<const F*>(K + (long)key * a.ldk + ks * KS + hh * VEC) : frag_zero<T>();
+        const F raw = key < a.S ? *reinterpret_cast<const F*>(K + (long)key * a.ldk + ks * KS + hh * VEC) : frag_zero<T>();
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) kf[ks][e] = from_f32<T>(to_f32(raw[e]) * sc2);
         vf[ks] = key < a.S ? *reinterpret_cast<const F*>(V + (long)key * a.ldv + ks * KS + hh * VEC) : frag_zero<T>();
     }
     const float kb2 = (a.key_bias && key < a.S) ? a.key_bias[(long)b * a.S + key] * LOG2E : 0.f;
-    const float sc2 = a.scale * LOG2E;
-    const bool win_on = a.window > 0 && a.window < a.T, drop = a.drop_thresh != 0;
-    const int kw0 = k0 + wave * 32;
+    const F kya = hh ? frag_zero<T>() : Aug<T>::y(kb2);         // key side of the score chain: the key bias
+    const F vya = hh ? frag_zero<T>() : Aug<T>::y(0.f);         // V side of the dP chain: the unit slots
+    const bool win_on = a.window > 0 && a.window < a.T;
     int lq = -1, lkv = 0;
     if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
-    const uint32_t bh_key = attn_bh_key(a, b, h), s2 = (uint32_t)(a.S + 1) >> 1, thr32 = a.drop_thresh << 16;
-    const uint32_t khalf = (uint32_t)key >> 1, kup = (key & 1) ? 0u : 16u;   // shift that moves this key's 16 random bits to the top
+    int vis_lo; unsigned vis_span;
+    visible_queries(a, key, lq, lkv, vis_lo, vis_span);
+    // dropout bits of this lane's key: one 32-bit column (bit = query & 31) of the (32-query, 64-key) tile's words
+    const int ko = lane & 31, nqb32 = (a.T + 31) >> 5;
+    const uint32_t* wcol = reinterpret_cast<const uint32_t*>(dmask) +
+                           2 * (drop_word_base(a, b * a.H + h, 0, min(kw0, a.S - 1) >> 6) + ((kw0 >> 5) & 1) * 16 + (ko & 3) + 4 * (ko >> 3)) + ((ko >> 2) & 1);
+    const long wq_stride = 2L * ((a.S + 63) >> 6) * 32;         // dwords between consecutive 32-query blocks
 
     f32x16 acc_k[NDB], acc_v[NDB];
 #pragma unroll
@@ -601,15 +729,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
     const long sbase = ((long)b * a.H + h) * a.T;
     RowTile<T, HD, BQ> qt, dt;
-    float lse_r = 0.f, del_r = 0.f;
+    float lse_r = 0.f, ndc_r = 0.f;
     auto prefetch = [&](int q0) {
         qt.load(Q, a.ldq, q0, a.T, tid);
         dt.load(DO, a.lddo, q0, a.T, tid);
         if (tid < BQ) {
             lse_r = q0 + tid < a.T ? a.lse[sbase + q0 + tid] * LOG2E : 0.f;
-            del_r = q0 + tid < a.T ? a.delta[sbase + q0 + tid] : 0.f;
+            if (!(lse_r > -INFINITY)) lse_r = 0.f;              // a row without a visible key: every P is zeroed by its mask below
+            ndc_r = q0 + tid < a.T ? -a.delta[sbase + q0 + tid] / a.drop_scale : 0.f;
         }
     };
+    if (tid == 0) { Qa[BQ] = frag_zero<T>(); Da[BQ] = frag_zero<T>(); }
     if (q_beg < q_end) prefetch(q_beg);
     for (int q0 = q_beg; q0 < q_end; q0 += BQ) {
         __syncthreads();
@@ -619,11 +749,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
             qt.template store_t<PT>(Qt, tid);
             dt.template store_t<PT>(Dt, tid);
         }
-        if (tid < BQ) { lse_s[tid] = lse_r; del_s[tid] = del_r; }
+        if (tid < BQ) { Qa[tid] = Aug<T>::x(-lse_r); Da[tid] = Aug<T>::x(ndc_r); ndc_s[tid] = ndc_r; }
         __syncthreads();
+        uint32_t wbits[BQ / 32];
+#pragma unroll
+        for (int mb = 0; mb < BQ / 32; ++mb) {                  // requested ahead of the next tile's rows: vmcnt is in order
+            const int qb32 = min((q0 >> 5) + mb, nqb32 - 1);
+            wbits[mb] = DROP ? wcol[qb32 * wq_stride] >> (4 * hh) : 0u;
+        }
         if (q0 + BQ < q_end) prefetch(q0 + BQ);
-#pragma unroll 1
-        for (int mb = 0; mb < BQ / 32; ++mb) {      // not unrolled: two 32-query blocks in flight would halve the occupancy
+#pragma unroll
+        for (int mb = 0; mb < BQ / 32; ++mb) {
             const int qb = q0 + mb * 32;
             if (qb >= q_end) break;                                     // block-uniform
             f32x16 st, dp;
@@ -636,50 +772,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
                 const F df = *reinterpret_cast<const F*>(&Ds[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
                 mma32(dp, df, vf[ks]);
             }
+            mma32(st, Qa[hh ? BQ : mb * 32 + (lane & 31)], kya);
+            mma32(dp, Da[hh ? BQ : mb * 32 + (lane & 31)], vya);
             f32x16 pd;  // dropped probabilities (for dV)
             const bool full = (kw0 + 32 <= a.S) && (qb + 32 <= a.T) && lq < 0 &&
                               (!a.causal || (kw0 + 31 <= qb && (!win_on || kw0 >= qb + 31 - a.window)));
-            // one fused pass per element (few live registers); the wave-uniform `plain` branch carries no mask / dropout code
-            if (full && !drop) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r]);            // P
+            if (!full) {
+                const int rel = qb + 4 * hh - vis_lo;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[r] = (unsigned)(rel + acc_row(r, 0)) < vis_span ? st[r] : 0.f;
+            }
+            if constexpr (DROP) {
+                const uint32_t wb = wbits[mb];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lse_s[mb * 32 + 8 * g + 4 * hh]);   // already * log2 e
-                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(&del_s[mb * 32 + 8 * g + 4 * hh]);
+                    const f32x4 n4 = *reinterpret_cast<const f32x4*>(&ndc_s[mb * 32 + 8 * g + 4 * hh]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * g + e;
-                        const float pv = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, kb2) - l4[e]);
-                        pd[r] = pv;
-                        st[r] = pv * (dp[r] - d4[e]);    // dS
+                        // (scalar copies first: __builtin_bit_cast applied to a vector ELEMENT expression read element 0 -- hipcc 7.2)
+                        const uint32_t m = 0u - ((wb >> (8 * g + e)) & 1u);                                      // all ones: kept
+                        const float pv = st[r], dv = dp[r], nv = n4[e];
+                        pd[r] = __uint_as_float(__float_as_uint(pv) & m);
+                        const float t = __uint_as_float((__float_as_uint(dv) & m) | (__float_as_uint(nv) & ~m));
+                        st[r] *= t;                                                                      // dS / c
                     }
                 }
             } else {
-                // The hash of (query, key >> 1) serves both lanes of a key pair (lane, lane ^ 1): each lane computes it for
-                // every other query register and the two swap through a DPP quad permute.
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lse_s[mb * 32 + 8 * g + 4 * hh]);
-                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(&del_s[mb * 32 + 8 * g + 4 * hh]);
-                    uint32_t xr[4] = {0u, 0u, 0u, 0u};
-                    if (drop) {
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const uint32_t x = attn_rand2(bh_key, (uint32_t)(qb + 8 * g + 4 * hh + 2 * j + (lane & 1)) * s2 + khalf);
-                            const uint32_t y = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                            xr[2 * j] = (lane & 1) ? y : x;
-                            xr[2 * j + 1] = (lane & 1) ? x : y;
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g + e, qq = qb + 8 * g + 4 * hh + e;
-                        float pv = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, kb2) - l4[e]);
-                        if (!full && !attn_visible(a, qq, key, lq, lkv)) pv = 0.f;
-                        const bool keep = !drop || (xr[e] << kup) >= thr32;
-                        pd[r] = keep ? pv : 0.f;                 // rescaled by 1/(1-p) in the epilogue
-                        st[r] = pv * (keep ? fmaf(dp[r], a.drop_scale, -d4[e]) : -d4[e]);    // dS = P o (M o dP / (1-p) - delta)
-                    }
-                }
+                for (int r = 0; r < 16; ++r) { pd[r] = st[r]; st[r] *= dp[r]; }
             }
 #pragma unroll
             for (int s = 0; s < NFR; ++s) {
@@ -696,6 +819,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         }
     }
     // accumulators: column = d (lane & 31), row = key (register axis)
+    const float ksc = a.scale * a.drop_scale;
 #pragma unroll
     for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -703,7 +827,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
             const int kk = k0 + wave * 32 + acc_row(r, lane);
             if (kk >= a.S) continue;
             const int col = h * HD + d * 32 + (lane & 31);
-            ((T*)a.dk)[(long)b * a.bsdk + (long)kk * a.lddk + col] = from_f32<T>(acc_k[d][r] * a.scale);
+            ((T*)a.dk)[(long)b * a.bsdk + (long)kk * a.lddk + col] = from_f32<T>(acc_k[d][r] * ksc);
             ((T*)a.dv)[(long)b * a.bsdv + (long)kk * a.lddv + col] = from_f32<T>(acc_v[d][r] * a.drop_scale);
         }
 }
@@ -721,15 +845,44 @@ __global__ void attn_dropout_mask_kernel(unsigned char* __restrict__ out, AttnAr
     }
 }
 
+// The keep bits in the kernels' word layout (drop_word_base): one wave per (b, h, 32-query block, 64-key tile) evaluates the
+// pair hash in the forward kernel's lane layout (lane = query + 32 * k-half, register = key) and turns each register's
+// comparison into its 64-bit lane mask -- v_cmp writes exactly that word.
+__global__ __launch_bounds__(256) void attn_dropout_words_kernel(uint64_t* __restrict__ out, AttnArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5;
+    const int nkt = (a.S + 63) >> 6, kt = blockIdx.x * 4 + wave;
+    if (kt >= nkt) return;                                       // wave-uniform
+    const int qb32 = blockIdx.y, bh = blockIdx.z;
+    const uint32_t bh_key = hash32((uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)bh);
+    const uint32_t s2 = (uint32_t)(a.S + 1) >> 1, thr32 = a.drop_thresh << 16;
+    const uint32_t pbase = (uint32_t)(qb32 * 32 + (lane & 31)) * s2 + (uint32_t)((kt * 64 + 4 * hh) >> 1);
+    uint64_t mine = 0;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {     // registers 2j, 2j+1 of a block are adjacent keys: one hash per pair
+            const uint32_t x = attn_rand2(bh_key, pbase + (uint32_t)((mb * 32 + acc_row(2 * j, 0)) >> 1));
+            const uint64_t w0 = __builtin_amdgcn_ballot_w64(attn_keep_lo(x, thr32));
+            const uint64_t w1 = __builtin_amdgcn_ballot_w64(attn_keep_hi(x, thr32));
+            if (lane == mb * 16 + 2 * j) mine = w0;
+            if (lane == mb * 16 + 2 * j + 1) mine = w1;
+        }
+    if (lane < 32) out[drop_word_base(a, bh, qb32, kt) + lane] = mine;
+}
+
 template <typename T, int HD> int run_fwd(const AttnArgs& a, hipStream_t s, bool merge = true) {
-    if (a.T <= 32 && a.S > 64) {        // a single 32-row query block: split the keys over the waves (and, with a workspace, over workgroups)
-        hipLaunchKernelGGL((attn_fwd_kernel<T, HD, true>), dim3(a.nsplit > 1 ? a.nsplit : 1, a.H, a.B), dim3(256), 0, s, a);
+    // a single 32-row query block (KV-cached decode): split the keys over the waves (and, with a workspace, over workgroups).
+    // Inference only: a training forward with dropout and T <= 32 takes the query-per-wave kernel below.
+    if (a.T <= 32 && a.S > 64 && !a.drop_thresh) {
+        const dim3 g(a.nsplit > 1 ? a.nsplit : 1, a.H, a.B);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, HD, true, false>), g, dim3(256), 0, s, a, a.dmask);
         if (a.nsplit > 1 && merge) hipLaunchKernelGGL((attn_split_merge_kernel<T, HD>), dim3(a.B * a.H * a.T), dim3(64), 0, s, a);
         OMR_CHECK_LAUNCH();
         return OMR_OK;
     }
     dim3 grid(cdiv(a.T, 128) * (a.nsplit > 1 ? a.nsplit : 1), a.H, a.B);
-    hipLaunchKernelGGL((attn_fwd_kernel<T, HD, false>), grid, dim3(256), 0, s, a);
+    if (a.drop_thresh) hipLaunchKernelGGL((attn_fwd_kernel<T, HD, false, true>), grid, dim3(256), 0, s, a, a.dmask);
+    else hipLaunchKernelGGL((attn_fwd_kernel<T, HD, false, false>), grid, dim3(256), 0, s, a, a.dmask);
     if (a.nsplit > 1) hipLaunchKernelGGL((attn_split_merge_kernel<T, HD>), dim3(a.B * a.H * a.T), dim3(64), 0, s, a);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
@@ -737,18 +890,22 @@ template <typename T, int HD> int run_fwd(const AttnArgs& a, hipStream_t s, bool
 template <typename T, int HD> int run_bwd(const AttnArgs& a, hipStream_t s) {
     long n = (long)a.B * a.H * a.T;
     hipLaunchKernelGGL((attn_delta_kernel<T, HD>), cdiv(n, 256), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), dim3(cdiv(a.T, 128) * (a.nsplit > 1 ? a.nsplit : 1), a.H, a.B), dim3(256), 0, s, a);
+    const dim3 gq(cdiv(a.T, 128) * (a.nsplit > 1 ? a.nsplit : 1), a.H, a.B);
+    if (a.drop_thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD, true>), gq, dim3(256), 0, s, a, a.dmask);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD, false>), gq, dim3(256), 0, s, a, a.dmask);
     if (a.nsplit > 1) {
         long nsum = (long)a.B * a.T * a.H * HD, gs = (nsum + 255) / 256;
         hipLaunchKernelGGL((attn_dq_sum_kernel<T>), dim3((unsigned)(gs > 4096 ? 4096 : gs)), dim3(256), 0, s, a, HD);
     }
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD>), dim3(cdiv(a.S, 128), a.H, a.B), dim3(256), 0, s, a);
+    const dim3 gk(cdiv(a.S, 128), a.H, a.B);
+    if (a.drop_thresh) hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD, true>), gk, dim3(256), 0, s, a, a.dmask);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD, false>), gk, dim3(256), 0, s, a, a.dmask);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }
 
 int fill_common(AttnArgs& a, int B, int H, int T, int S, int hd, float dropout_p, unsigned long long seed, int causal, int window,
-                const float* key_bias, const int* blk_lq, const int* blk_lkv) {
+                const float* key_bias, const int* blk_lq, const int* blk_lkv, const unsigned long long* drop_words = nullptr, bool need_words = false) {
     if (B <= 0 || H <= 0 || T <= 0 || S <= 0) return OMR_ERR_ARG;
     if (hd != 32 && hd != 64) return OMR_ERR_UNSUPPORTED;
     if (dropout_p < 0.f || dropout_p >= 1.f) return OMR_ERR_ARG;
@@ -758,6 +915,8 @@ int fill_common(AttnArgs& a, int B, int H, int T, int S, int hd, float dropout_p
     a.drop_thresh = (uint32_t)((double)dropout_p * 65536.0 + 0.5);      // 16-bit threshold (attn_rand2); 0 = dropout off
     a.drop_scale = 1.f / (1.f - dropout_p);
     a.seed = seed;
+    a.dmask = reinterpret_cast<const uint64_t*>(drop_words);
+    if (need_words && a.drop_thresh != 0 && !drop_words) return OMR_ERR_ARG;      // the kernels read the keep bits, they do not hash
     return OMR_OK;
 }
 
@@ -771,6 +930,22 @@ extern "C" int omr_attn_dropout_mask(unsigned char* mask, int B, int H, int T, i
     const long n = (long)B * H * T * S;
     long g = (n + 255) / 256; if (g > 4096) g = 4096;
     hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, mask, a);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+extern "C" long omr_attn_dropout_words_count(int B, int H, int T, int S) {
+    if (B <= 0 || H <= 0 || T <= 0 || S <= 0) return 0;
+    return (long)B * H * ((T + 31) / 32) * ((S + 63) / 64) * 32;
+}
+
+extern "C" int omr_attn_dropout_words(unsigned long long* words, int B, int H, int T, int S, float dropout_p, unsigned long long seed, void* stream) {
+    AttnArgs a = {};
+    int rc = fill_common(a, B, H, T, S, 64, dropout_p, seed, 0, -1, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if (!words || a.drop_thresh == 0) return OMR_ERR_ARG;
+    const dim3 grid((unsigned)(((S + 63) / 64 + 3) / 4), (unsigned)((T + 31) / 32), (unsigned)(B * H));
+    hipLaunchKernelGGL(attn_dropout_words_kernel, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<uint64_t*>(words), a);
     OMR_CHECK_LAUNCH();
     return OMR_OK;
 }
@@ -811,24 +986,24 @@ extern "C" long omr_attn_workspace_floats(int B, int H, int T, int S, int head_d
 static int attn_fwd_impl(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                          long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
                          const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed,
-                         float* split_ws, long split_ws_floats, void* stream, int* nsplit_out = nullptr);
+                         const unsigned long long* drop_words, float* split_ws, long split_ws_floats, void* stream, int* nsplit_out = nullptr);
 
 /* omr_attn_fwd with caller-provided scratch for the key split (omr_attn_workspace_floats(..., backward = 0) floats) */
 extern "C" int omr_attn_fwd_ws(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                                long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
                                const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed,
-                               float* ws, long ws_floats, void* stream) {
+                               const unsigned long long* drop_words, float* ws, long ws_floats, void* stream) {
     return attn_fwd_impl(dtype, q, k, v, o, lse, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, T, S, head_dim, causal, window, key_bias, blk_lq, blk_lkv,
-                         dropout_p, seed, ws, ws_floats, stream);
+                         dropout_p, seed, drop_words, ws, ws_floats, stream);
 }
 
 
 extern "C" int omr_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                             long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
                             const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed,
-                            void* stream) {
+                            const unsigned long long* drop_words, void* stream) {
     return attn_fwd_impl(dtype, q, k, v, o, lse, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, T, S, head_dim, causal, window, key_bias, blk_lq, blk_lkv,
-                         dropout_p, seed, nullptr, 0, stream);
+                         dropout_p, seed, drop_words, nullptr, 0, stream);
 }
 
 /* floats of split workspace omr_attn_fwd_split wants for (B, H, T <= 32, S): partial softmaxes of the key splits */
@@ -844,15 +1019,15 @@ extern "C" int omr_attn_fwd_split(int dtype, const void* q, const void* k, const
                                   float* split_ws, long split_ws_floats, void* stream) {
     if (T > 32) return OMR_ERR_ARG;
     return attn_fwd_impl(dtype, q, k, v, o, lse, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, T, S, head_dim, 0, -1, key_bias, nullptr, nullptr, 0.f, 0,
-                         split_ws, split_ws_floats, stream);
+                         nullptr, split_ws, split_ws_floats, stream);
 }
 
 static int attn_fwd_impl(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, long ldq, long ldk, long ldv, long ldo,
                          long bsq, long bsk, long bsv, long bso, int B, int H, int T, int S, int head_dim, int causal, int window,
                          const float* key_bias, const int* blk_lq, const int* blk_lkv, float dropout_p, unsigned long long seed,
-                         float* split_ws, long split_ws_floats, void* stream, int* nsplit_out) {
+                         const unsigned long long* drop_words, float* split_ws, long split_ws_floats, void* stream, int* nsplit_out) {
     AttnArgs a = {};
-    int rc = fill_common(a, B, H, T, S, head_dim, dropout_p, seed, causal, window, key_bias, blk_lq, blk_lkv);
+    int rc = fill_common(a, B, H, T, S, head_dim, dropout_p, seed, causal, window, key_bias, blk_lq, blk_lkv, drop_words, true);
     if (rc) return rc;
     const int vec = dtype == OMR_BF16 ? 8 : 4;
     if (ldq % vec || ldk % vec || ldv % vec || ldo % 4) return OMR_ERR_ARG;
@@ -884,16 +1059,16 @@ extern "C" int omr_attn_fwd_split_partials(int dtype, const void* q, const void*
                                            float* split_ws, long split_ws_floats, int* nsplit, void* stream) {
     if (T > 32 || !nsplit) return OMR_ERR_ARG;
     return attn_fwd_impl(dtype, q, k, v, o, lse, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, T, S, head_dim, 0, -1, nullptr, nullptr, nullptr, 0.f, 0,
-                         split_ws, split_ws_floats, stream, nsplit);
+                         nullptr, split_ws, split_ws_floats, stream, nsplit);
 }
 
 extern "C" int omr_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                             float* delta_ws, void* dq, void* dk, void* dv, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq,
                             long lddk, long lddv, long bsq, long bsk, long bsv, long bso, long bsdo, long bsdq, long bsdk, long bsdv, int B,
                             int H, int T, int S, int head_dim, int causal, int window, const float* key_bias, const int* blk_lq,
-                            const int* blk_lkv, float dropout_p, unsigned long long seed, void* stream) {
+                            const int* blk_lkv, float dropout_p, unsigned long long seed, const unsigned long long* drop_words, void* stream) {
     return omr_attn_bwd_ws(dtype, q, k, v, o, dout, lse, delta_ws, dq, dk, dv, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, bsq, bsk, bsv, bso, bsdo, bsdq,
-                           bsdk, bsdv, B, H, T, S, head_dim, causal, window, key_bias, blk_lq, blk_lkv, dropout_p, seed, nullptr, 0, stream);
+                           bsdk, bsdv, B, H, T, S, head_dim, causal, window, key_bias, blk_lq, blk_lkv, dropout_p, seed, drop_words, nullptr, 0, stream);
 }
 
 /* omr_attn_bwd with caller-provided scratch for the key split of the dQ kernel (omr_attn_workspace_floats(..., backward = 1)) */
@@ -901,9 +1076,10 @@ extern "C" int omr_attn_bwd_ws(int dtype, const void* q, const void* k, const vo
                                float* delta_ws, void* dq, void* dk, void* dv, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq,
                                long lddk, long lddv, long bsq, long bsk, long bsv, long bso, long bsdo, long bsdq, long bsdk, long bsdv, int B,
                                int H, int T, int S, int head_dim, int causal, int window, const float* key_bias, const int* blk_lq,
-                               const int* blk_lkv, float dropout_p, unsigned long long seed, float* ws, long ws_floats, void* stream) {
+                               const int* blk_lkv, float dropout_p, unsigned long long seed, const unsigned long long* drop_words, float* ws,
+                               long ws_floats, void* stream) {
     AttnArgs a = {};
-    int rc = fill_common(a, B, H, T, S, head_dim, dropout_p, seed, causal, window, key_bias, blk_lq, blk_lkv);
+    int rc = fill_common(a, B, H, T, S, head_dim, dropout_p, seed, causal, window, key_bias, blk_lq, blk_lkv, drop_words, true);
     if (rc) return rc;
     const int vec = dtype == OMR_BF16 ? 8 : 4;
     if (ldq % vec || ldk % vec || ldv % vec || lddo % vec) return OMR_ERR_ARG;

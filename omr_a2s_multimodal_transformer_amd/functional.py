@@ -288,9 +288,13 @@ class AttentionFn(Function):
         else:
             d = q_or_qkv.shape[-1]
             q, k, v = q_or_qkv, kv[..., :d], kv[..., d:]
+        # attention-probability dropout: the keep bits of this (layer, step) are generated once, in the word layout all three
+        # kernels read (K.attn_dropout_words), and kept for the backward pass
+        words = K.attn_dropout_words(q.shape[0], nhead, q.shape[1], k.shape[1], dropout_p, seed, q.device) if dropout_p > 0.0 else None
         o, lse = K.attn_fwd(q, k, v, nhead, causal=causal, window=window, key_bias=key_bias, blk_lq=blk_lq, blk_lkv=blk_lkv,
-                            dropout_p=dropout_p, seed=seed)
+                            dropout_p=dropout_p, seed=seed, drop_words=words)
         ctx.cfg = (nhead, causal, window, dropout_p, seed, kv is None, d)
+        ctx.drop_words = words
         ctx.kv_sink = getattr(kv, "omr_grad_sink", None) if kv is not None else None     # (KVGradSink, layer): see FusedCrossKVFn
         ctx.save_for_backward(q_or_qkv, kv, o, lse, key_bias, blk_lq, blk_lkv)
         return o
@@ -311,7 +315,7 @@ class AttentionFn(Function):
             q, k, v = q_or_qkv, kv[..., :d], kv[..., d:]
             dq, dk, dv = dqkv, dkv[..., :d], dkv[..., d:]
         K.attn_bwd(q, k, v, o, go, lse, dq, dk, dv, nhead, causal=causal, window=window, key_bias=key_bias, blk_lq=blk_lq, blk_lkv=blk_lkv,
-                   dropout_p=dropout_p, seed=seed)
+                   dropout_p=dropout_p, seed=seed, drop_words=ctx.drop_words)
         return dqkv, dkv, None, None, None, None, None, None, None, None
 
 

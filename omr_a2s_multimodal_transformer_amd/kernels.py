@@ -518,9 +518,20 @@ def _bts(t: Tensor) -> Tuple[int, int]:
     return t.stride(1), t.stride(0)
 
 
+def attn_dropout_words(B: int, H: int, T: int, S: int, p: float, seed: int, device) -> Tensor:
+    """The keep bits of the attention-probability dropout for (p, seed) in the kernels' word layout (omr_attn_dropout_words):
+    int64 [omr_attn_dropout_words_count].  Generated once per (layer, step); forward and backward read the same buffer."""
+    n = lib().query("omr_attn_dropout_words_count", B, H, T, S)
+    out = torch.empty(n, dtype=torch.int64, device=device)
+    lib().call("omr_attn_dropout_words", ptr(out), B, H, T, S, float(p), int(seed) & (2**64 - 1), cur_stream())
+    return out
+
+
 def attn_fwd(q: Tensor, k: Tensor, v: Tensor, nhead: int, *, causal: bool = False, window: int = -1, key_bias: Optional[Tensor] = None,
-             blk_lq: Optional[Tensor] = None, blk_lkv: Optional[Tensor] = None, dropout_p: float = 0.0, seed: int = 0):
-    """q [B,T,d], k/v [B,S,d] (may be strided views of packed projections) -> (o [B,T,d], lse [B,H,T])."""
+             blk_lq: Optional[Tensor] = None, blk_lkv: Optional[Tensor] = None, dropout_p: float = 0.0, seed: int = 0,
+             drop_words: Optional[Tensor] = None):
+    """q [B,T,d], k/v [B,S,d] (may be strided views of packed projections) -> (o [B,T,d], lse [B,H,T]).  dropout_p > 0: the keep
+    bits come from drop_words (attn_dropout_words; generated here from (dropout_p, seed) when not given)."""
     require_cuda(q, k, v, key_bias, blk_lq, blk_lkv)
     B, T, d = q.shape
     S = k.shape[1]
@@ -535,8 +546,11 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, nhead: int, *, causal: bool = Fals
             assert t.dtype == torch.int32 and t.numel() == B and t.is_contiguous()
     (ldq, bsq), (ldk, bsk), (ldv, bsv), (ldo, bso) = _bts(q), _bts(k), _bts(v), _bts(o)
     ws, nws = _attn_ws(B, nhead, T, S, hd, causal, False, q.device)
+    if dropout_p > 0.0 and drop_words is None:
+        drop_words = attn_dropout_words(B, nhead, T, S, dropout_p, seed, q.device)
     lib().call("omr_attn_fwd_ws", dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, nhead, T, S, hd,
-               int(causal), int(window), ptr(key_bias), ptr(blk_lq), ptr(blk_lkv), float(dropout_p), int(seed) & (2**64 - 1), ptr(ws), nws, cur_stream())
+               int(causal), int(window), ptr(key_bias), ptr(blk_lq), ptr(blk_lkv), float(dropout_p), int(seed) & (2**64 - 1), ptr(drop_words), ptr(ws), nws,
+               cur_stream())
     return o, lse
 
 
@@ -567,7 +581,7 @@ def _attn_ws(B: int, H: int, T: int, S: int, hd: int, causal: bool, backward: bo
 
 
 def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, nhead: int, *, causal=False, window=-1, key_bias=None, blk_lq=None, blk_lkv=None,
-             dropout_p: float = 0.0, seed: int = 0) -> None:
+             dropout_p: float = 0.0, seed: int = 0, drop_words: Optional[Tensor] = None) -> None:
     """Writes dq [B,T,d], dk/dv [B,S,d] (views allowed, unit inner stride)."""
     require_cuda(q, k, v, o, dout, dq, dk, dv)
     B, T, d = q.shape
@@ -578,9 +592,11 @@ def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, nhead: int, *, causal=False, win
     (ldq, bsq), (ldk, bsk), (ldv, bsv), (ldo, bso), (lddo, bsdo) = _bts(q), _bts(k), _bts(v), _bts(o), _bts(dout)
     (lddq, bsdq), (lddk, bsdk), (lddv, bsdv) = _bts(dq), _bts(dk), _bts(dv)
     ws, nws = _attn_ws(B, nhead, T, S, hd, causal, True, q.device)
+    if dropout_p > 0.0 and drop_words is None:
+        drop_words = attn_dropout_words(B, nhead, T, S, dropout_p, seed, q.device)
     lib().call("omr_attn_bwd_ws", dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ldq, ldk,
                ldv, ldo, lddo, lddq, lddk, lddv, bsq, bsk, bsv, bso, bsdo, bsdq, bsdk, bsdv, B, nhead, T, S, hd, int(causal), int(window),
-               ptr(key_bias), ptr(blk_lq), ptr(blk_lkv), float(dropout_p), int(seed) & (2**64 - 1), ptr(ws), nws, cur_stream())
+               ptr(key_bias), ptr(blk_lq), ptr(blk_lkv), float(dropout_p), int(seed) & (2**64 - 1), ptr(drop_words), ptr(ws), nws, cur_stream())
 
 
 def attn_dropout_mask(B: int, H: int, T: int, S: int, p: float, seed: int, device) -> Tensor:
