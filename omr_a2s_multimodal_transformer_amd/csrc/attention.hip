@@ -11,6 +11,7 @@
 //   S^T = K . Q^T        (A = K tile from LDS, B = Q fragments held in registers)      -> softmax is lane-local
 //   O^T += V^T . P^T     (A = V^T tile from LDS, B = P^T straight from the accumulator registers, permuted-k order)
 // Backward: dQ kernel (same orientation) and dK/dV kernel (queries on the register axis, keys on the lanes).
+#include <cstdlib>
 #include <type_traits>
 
 #include "omr_common.h"
@@ -83,36 +84,36 @@ template <typename T> __device__ __forceinline__ typename Frag<T>::type acc_to_f
     return f;
 }
 
-// Register-staged tile of NR rows x HD: load() issues the global reads (rows beyond nrows read as zero), store() /
-// store_t() commit them to LDS row-major / transposed.  The kernels load tile t+1 right after the barrier that publishes
-// tile t, so the HBM latency of the next tile is hidden behind the MFMA / softmax work on the current one.
+// Register-staged tile of NR rows x HD: load() issues the global reads, store() / store_t() commit them to LDS row-major /
+// transposed.  The kernels load tile t+1 right after the barrier that publishes tile t, so the HBM latency of the next tile
+// is hidden behind the MFMA / softmax work on the current one.  Rows at or beyond nrows read the LAST VALID row instead
+// (finite data; every consumer masks those rows' scores): the loads carry no per-lane condition -- a conditional load
+// compiles to an exec-masked branch per chunk and pessimistic waits behind it.
 template <typename T, int HD, int NR> struct RowTile {
     typedef typename Frag<T>::type F;
-    static constexpr int VEC = Frag<T>::N, CPR = HD / VEC, NCH = (NR * CPR + 255) / 256;
+    static constexpr int VEC = Frag<T>::N, CPR = HD / VEC, NCH = (NR * CPR) / 256;
+    static_assert((NR * CPR) % 256 == 0, "every thread owns the same number of 16-byte chunks");
     F r[NCH];
     __device__ __forceinline__ void load(const T* src, long ld, int r0, int nrows, int tid) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * 256, row = c / CPR, kc = (c % CPR) * VEC;
-            r[i] = frag_zero<T>();
-            if (c < NR * CPR && r0 + row < nrows) r[i] = *reinterpret_cast<const F*>(src + (long)(r0 + row) * ld + kc);
+            r[i] = *reinterpret_cast<const F*>(src + (long)min(r0 + row, nrows - 1) * ld + kc);
         }
     }
     template <int P> __device__ __forceinline__ void store(T* lds, int tid) const {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * 256, row = c / CPR, kc = (c % CPR) * VEC;
-            if (c < NR * CPR) *reinterpret_cast<F*>(lds + row * P + kc) = r[i];
+            *reinterpret_cast<F*>(lds + row * P + kc) = r[i];
         }
     }
     template <int P> __device__ __forceinline__ void store_t(T* lds, int tid) const {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + i * 256, row = c / CPR, kc = (c % CPR) * VEC;
-            if (c < NR * CPR) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) lds[(kc + e) * P + row] = r[i][e];
-            }
+            for (int e = 0; e < VEC; ++e) lds[(kc + e) * P + row] = r[i][e];
         }
     }
 };
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a, const uint
     auto prefetch = [&](int kvb) {
         kt.load(K, a.ldk, kvb, a.S, tid);
         vt.load(V, a.ldv, kvb, a.S, tid);
-        if (tid < BST) bias_r = (a.key_bias && kvb + tid < a.S) ? a.key_bias[(long)b * a.S + kvb + tid] * LOG2E : 0.f;
+        if (tid < BST) bias_r = a.key_bias ? a.key_bias[(long)b * a.S + min(kvb + tid, a.S - 1)] * LOG2E : 0.f;     // keys >= S: masked
     };
     if (tid == 0) Ka[BST] = frag_zero<T>();
     if (kv_beg < kv_end) prefetch(kv_beg);
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a, const u
     auto prefetch = [&](int kv0) {
         kt.load(K, a.ldk, kv0, a.S, tid);
         vt.load(V, a.ldv, kv0, a.S, tid);
-        if (tid < BKV) bias_r = (a.key_bias && kv0 + tid < a.S) ? a.key_bias[(long)b * a.S + kv0 + tid] * LOG2E : 0.f;
+        if (tid < BKV) bias_r = a.key_bias ? a.key_bias[(long)b * a.S + min(kv0 + tid, a.S - 1)] * LOG2E : 0.f;     // keys >= S: masked
     };
     if (tid == 0) Ka[BKV] = frag_zero<T>();
     if (kv_beg < kv_end) prefetch(kv_beg);
@@ -733,10 +734,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a, const 
     auto prefetch = [&](int q0) {
         qt.load(Q, a.ldq, q0, a.T, tid);
         dt.load(DO, a.lddo, q0, a.T, tid);
-        if (tid < BQ) {
-            lse_r = q0 + tid < a.T ? a.lse[sbase + q0 + tid] * LOG2E : 0.f;
+        if (tid < BQ) {                                         // rows >= T: masked
+            const int qq = min(q0 + tid, a.T - 1);
+            lse_r = a.lse[sbase + qq] * LOG2E;
             if (!(lse_r > -INFINITY)) lse_r = 0.f;              // a row without a visible key: every P is zeroed by its mask below
-            ndc_r = q0 + tid < a.T ? -a.delta[sbase + q0 + tid] / a.drop_scale : 0.f;
+            ndc_r = -a.delta[sbase + qq] / a.drop_scale;
         }
     };
     if (tid == 0) { Qa[BQ] = frag_zero<T>(); Da[BQ] = frag_zero<T>(); }
@@ -963,7 +965,8 @@ static void choose_split(int B, int H, int T, int S, int causal, int* nsplit, in
     if (T <= 32) { want = (S + 255) / 256; if (want > 64) want = 64; }      // the merge prologue of omr_decode_linear takes <= 64 splits
     else {
         const long blocks = (long)B * H * ((T + 127) / 128);
-        want = (int)((512 + blocks - 1) / blocks);               // at least ~512 workgroups (2 per CU); more buys nothing: the
+        static const int min_wg = getenv("OMR_ATTN_MIN_WG") ? atoi(getenv("OMR_ATTN_MIN_WG")) : 512;      // experiment knob
+        want = (int)((min_wg + blocks - 1) / blocks);               // at least ~512 workgroups (2 per CU); more buys nothing: the
                                                                   // kernels are VALU-issue bound, not latency bound (measured)
         const int maxs = S / 512;                                 // at least 512 keys per split
         if (want > maxs) want = maxs;
