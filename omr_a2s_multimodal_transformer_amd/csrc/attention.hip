@@ -40,6 +40,8 @@ struct AttnArgs {
 };
 
 template <typename T> struct ACfg {
+    static constexpr int MPI = std::is_same<T, bf16>::value ? 1 : 4;      // MFMA instructions per mma32 (sched_group_barrier counts)
+    static constexpr int RPF = std::is_same<T, bf16>::value ? 2 : 1;      // LDS reads per permuted-k fragment (kperm_frag)
     static constexpr int VEC = Frag<T>::N;
     static constexpr int NFR = 16 / VEC;   // operand fragments per 32-wide accumulator block (2 bf16 / 4 fp32)
 };
@@ -312,16 +314,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a, const uint
 
         // scores in the log2 domain, already relative to the row's reference:  s * scale * log2 e + bias - m_ref
         f32x16 st[2];
+        {   // every LDS operand of the two score chains is requested before the first MFMA (one LDS latency, counted waits)
+            F kfr[2][NKS + 1];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+            for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[mb][r] = 0.f;
+                for (int r = 0; r < 16; ++r) st[mb][r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const F kf = *reinterpret_cast<const F*>(&Ks[(kboff + mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
-                mma32(st[mb], kf, qf[ks]);
+                for (int ks = 0; ks < NKS; ++ks)
+                    kfr[mb][ks] = *reinterpret_cast<const F*>(&Ks[(kboff + mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
+                kfr[mb][NKS] = Ka[hh ? BST : kboff + mb * 32 + (lane & 31)];
             }
-            mma32(st[mb], Ka[hh ? BST : kboff + mb * 32 + (lane & 31)], qa);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (NKS + 1), 0);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) mma32(st[mb], kfr[mb][ks], qf[ks]);
+                mma32(st[mb], kfr[mb][NKS], qa);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * (NKS + 1) * ACfg<T>::MPI, 0);
         }
         // The tile's dropout words are requested HERE: scalar loads share lgkmcnt with the LDS reads and return out of order, so
         // the next wait on an LDS operand also waits for them -- behind the score chain the next LDS read is the first V
@@ -580,15 +591,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a, const u
         for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { st[mb][r] = 0.f; dp[mb][r] = 0.f; }
+            if constexpr (TRD) {   // the block's LDS operands first, then its two chains (one LDS latency per block, counted waits)
+                F kfr[NKS + 1], vfr[NKS];
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const F kf = *reinterpret_cast<const F*>(&Ks[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
-                mma32(st[mb], kf, qf[ks]);
-                const F vf = *reinterpret_cast<const F*>(&Vs[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
-                mma32(dp[mb], vf, dof[ks]);
+                for (int ks = 0; ks < NKS; ++ks) {
+                    kfr[ks] = *reinterpret_cast<const F*>(&Ks[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
+                    vfr[ks] = *reinterpret_cast<const F*>(&Vs[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
+                }
+                kfr[NKS] = Ka[hh ? BKV : mb * 32 + (lane & 31)];
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NKS + 1, 0);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    mma32(st[mb], kfr[ks], qf[ks]);
+                    mma32(dp[mb], vfr[ks], dof[ks]);
+                }
+                mma32(st[mb], kfr[NKS], qa);
+                mma32(dp[mb], va, da);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * NKS + 2, 0);
+            } else {               // fp32 (parity mode): the registers do not hold twice the fragments
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const F kf = *reinterpret_cast<const F*>(&Ks[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
+                    mma32(st[mb], kf, qf[ks]);
+                    const F vf = *reinterpret_cast<const F*>(&Vs[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
+                    mma32(dp[mb], vf, dof[ks]);
+                }
+                mma32(st[mb], Ka[hh ? BKV : mb * 32 + (lane & 31)], qa);
+                mma32(dp[mb], va, da);
             }
-            mma32(st[mb], Ka[hh ? BKV : mb * 32 + (lane & 31)], qa);
-            mma32(dp[mb], va, da);
         }
         // dropout words: requested behind the last LDS operand of the score / dP chains (see the forward kernel), consumed
         // behind the 32 exp2
@@ -621,13 +651,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a, const u
         for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[mb][r] *= dp[mb][r];                 // dS^T / c
+            if constexpr (TRD) {
+                F ktf[NFR][NDB];
 #pragma unroll
-            for (int s = 0; s < NFR; ++s) {
-                const F sf = acc_to_frag<T>(st[mb], s);
+                for (int s = 0; s < NFR; ++s)
 #pragma unroll
-                for (int d = 0; d < NDB; ++d) {
-                    const F kf = kperm_frag<T>(Ks, PK, Kt, PV, mb * 32, s, d * 32, lane);
-                    mma32(acc_q[d], kf, sf);
+                    for (int d = 0; d < NDB; ++d) ktf[s][d] = kperm_frag<T>(Ks, PK, Kt, PV, mb * 32, s, d * 32, lane);
+                __builtin_amdgcn_sched_group_barrier(0x100, NFR * NDB * ACfg<T>::RPF, 0);
+#pragma unroll
+                for (int s = 0; s < NFR; ++s) {
+                    const F sf = acc_to_frag<T>(st[mb], s);
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) mma32(acc_q[d], ktf[s][d], sf);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NFR * NDB, 0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < NFR; ++s) {
+                    const F sf = acc_to_frag<T>(st[mb], s);
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) {
+                        const F kf = kperm_frag<T>(Ks, PK, Kt, PV, mb * 32, s, d * 32, lane);
+                        mma32(acc_q[d], kf, sf);
+                    }
                 }
             }
         }
@@ -767,15 +813,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a, const 
             f32x16 st, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+            if constexpr (TRD) {   // every LDS operand of the two chains is requested before the first MFMA: one LDS latency per block, not one per MFMA
+                F qfr[NKS + 1], dfr[NKS + 1];
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const F qf = *reinterpret_cast<const F*>(&Qs[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
-                mma32(st, qf, kf[ks]);
-                const F df = *reinterpret_cast<const F*>(&Ds[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
-                mma32(dp, df, vf[ks]);
+                for (int ks = 0; ks < NKS; ++ks) {
+                    qfr[ks] = *reinterpret_cast<const F*>(&Qs[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
+                    dfr[ks] = *reinterpret_cast<const F*>(&Ds[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
+                }
+                qfr[NKS] = Qa[hh ? BQ : mb * 32 + (lane & 31)];
+                dfr[NKS] = Da[hh ? BQ : mb * 32 + (lane & 31)];
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NKS + 2, 0);      // the DS reads ...
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    mma32(st, qfr[ks], kf[ks]);
+                    mma32(dp, dfr[ks], vf[ks]);
+                }
+                mma32(st, qfr[NKS], kya);
+                mma32(dp, dfr[NKS], vya);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * NKS + 2, 0);      // ... then the MFMAs
+            } else {               // fp32 (parity mode): twice the fragments; the registers do not hold them all
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const F qf = *reinterpret_cast<const F*>(&Qs[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
+                    mma32(st, qf, kf[ks]);
+                    const F df = *reinterpret_cast<const F*>(&Ds[(mb * 32 + (lane & 31)) * PK + ks * KS + hh * VEC]);
+                    mma32(dp, df, vf[ks]);
+                }
+                mma32(st, Qa[hh ? BQ : mb * 32 + (lane & 31)], kya);
+                mma32(dp, Da[hh ? BQ : mb * 32 + (lane & 31)], vya);
             }
-            mma32(st, Qa[hh ? BQ : mb * 32 + (lane & 31)], kya);
-            mma32(dp, Da[hh ? BQ : mb * 32 + (lane & 31)], vya);
             f32x16 pd;  // dropped probabilities (for dV)
             const bool full = (kw0 + 32 <= a.S) && (qb + 32 <= a.T) && lq < 0 &&
                               (!a.causal || (kw0 + 31 <= qb && (!win_on || kw0 >= qb + 31 - a.window)));
@@ -794,11 +860,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a, const 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * g + e;
-                        // (scalar copies first: __builtin_bit_cast applied to a vector ELEMENT expression read element 0 -- hipcc 7.2)
-                        const uint32_t m = 0u - ((wb >> (8 * g + e)) & 1u);                                      // all ones: kept
+                        // m = all ones where kept (v_bfe_i32); pd = P & m; t = kept ? dP' : -delta / c (v_bfi_b32); written as
+                        // instructions: the compiler's own lowering of the same expressions took twice as many
                         const float pv = st[r], dv = dp[r], nv = n4[e];
+                        uint32_t m;
+                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(wb), "n"(8 * g + e));
                         pd[r] = __uint_as_float(__float_as_uint(pv) & m);
-                        const float t = __uint_as_float((__float_as_uint(dv) & m) | (__float_as_uint(nv) & ~m));
+                        float t;
+                        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(t) : "v"(m), "v"(dv), "v"(nv));
                         st[r] *= t;                                                                      // dS / c
                     }
                 }
@@ -806,16 +875,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a, const 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { pd[r] = st[r]; st[r] *= dp[r]; }
             }
+            if constexpr (TRD) {
+                F dtf[NFR][NDB], qtf[NFR][NDB];
 #pragma unroll
-            for (int s = 0; s < NFR; ++s) {
-                const F pf = acc_to_frag<T>(pd, s);
-                const F sf = acc_to_frag<T>(st, s);
+                for (int s = 0; s < NFR; ++s)
 #pragma unroll
-                for (int d = 0; d < NDB; ++d) {
-                    const F dtf = kperm_frag<T>(Ds, PK, Dt, PT, mb * 32, s, d * 32, lane);
-                    mma32(acc_v[d], pf, dtf);
-                    const F qtf = kperm_frag<T>(Qs, PK, Qt, PT, mb * 32, s, d * 32, lane);
-                    mma32(acc_k[d], sf, qtf);
+                    for (int d = 0; d < NDB; ++d) {
+                        dtf[s][d] = kperm_frag<T>(Ds, PK, Dt, PT, mb * 32, s, d * 32, lane);
+                        qtf[s][d] = kperm_frag<T>(Qs, PK, Qt, PT, mb * 32, s, d * 32, lane);
+                    }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NFR * NDB * ACfg<T>::RPF, 0);
+#pragma unroll
+                for (int s = 0; s < NFR; ++s) {
+                    const F pf = acc_to_frag<T>(pd, s);
+                    const F sf = acc_to_frag<T>(st, s);
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) {
+                        mma32(acc_v[d], pf, dtf[s][d]);
+                        mma32(acc_k[d], sf, qtf[s][d]);
+                    }
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * NFR * NDB, 0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < NFR; ++s) {
+                    const F pf = acc_to_frag<T>(pd, s);
+                    const F sf = acc_to_frag<T>(st, s);
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) {
+                        const F dtf = kperm_frag<T>(Ds, PK, Dt, PT, mb * 32, s, d * 32, lane);
+                        mma32(acc_v[d], pf, dtf);
+                        const F qtf = kperm_frag<T>(Qs, PK, Qt, PT, mb * 32, s, d * 32, lane);
+                        mma32(acc_k[d], sf, qtf);
+                    }
                 }
             }
         }

@@ -290,7 +290,10 @@ class AttentionFn(Function):
             q, k, v = q_or_qkv, kv[..., :d], kv[..., d:]
         # attention-probability dropout: the keep bits of this (layer, step) are generated once, in the word layout all three
         # kernels read (K.attn_dropout_words), and kept for the backward pass
-        words = K.attn_dropout_words(q.shape[0], nhead, q.shape[1], k.shape[1], dropout_p, seed, q.device) if dropout_p > 0.0 else None
+        words = None
+        if dropout_p > 0.0:
+            B_, T_, S_, dev_ = q.shape[0], q.shape[1], k.shape[1], q.device
+            words = WgradStream.prepare(lambda: K.attn_dropout_words(B_, nhead, T_, S_, dropout_p, seed, dev_), dev_)
         o, lse = K.attn_fwd(q, k, v, nhead, causal=causal, window=window, key_bias=key_bias, blk_lq=blk_lq, blk_lkv=blk_lkv,
                             dropout_p=dropout_p, seed=seed, drop_words=words)
         ctx.cfg = (nhead, causal, window, dropout_p, seed, kv is None, d)

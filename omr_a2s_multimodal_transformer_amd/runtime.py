@@ -90,7 +90,7 @@ class WgradStream:
     errors in the point_conv weight gradients in front of the encoder's residual adds when the side stream lags)."""
 
     enabled = True
-    kinds = {"linear", "depthwise", "cross_kv", "conv"}     # which weight gradients take the side stream (tests narrow this)
+    kinds = {"linear", "depthwise", "cross_kv", "conv", "prepare"}     # what takes the side stream (tests narrow this)
     _side = {}
     _pending = {}          # device index -> the stream that has to wait
     _hold = []             # (event recorded behind the side-stream kernel, the tensors it reads)
@@ -128,6 +128,32 @@ class WgradStream:
         cls._hold.append((ev, tensors))
         cls._pending[dev] = main
         cls._at_end_of_backward()
+
+    @classmethod
+    def side_stream(cls, device) -> "torch.cuda.Stream":
+        side = cls._side.get(device.index)
+        if side is None:
+            side = cls._side[device.index] = torch.cuda.Stream(device=device)
+        return side
+
+    @classmethod
+    def prepare(cls, fn, device):
+        """Run fn() -- work that depends on NOTHING the main stream has in flight (the attention dropout words of a layer: a
+        function of the seed alone) -- on the side stream and make the main stream wait for it.  The host issues a step's
+        launches far ahead of the GPU, so the side stream runs fn while the main stream is still busy with earlier kernels
+        (the encoder's HBM-bound convolutions, the previous step's backward pass): its vector work hides there instead of
+        sitting in front of the consumer.  The result is allocated from the side stream's pool and marked as used by the
+        main stream, so the allocator recycles it only after the consumers that were queued when it was freed."""
+        if not (cls.enabled and "prepare" in cls.kinds and device.type == "cuda"):
+            return fn()
+        side, main = cls.side_stream(device), torch.cuda.current_stream(device)
+        with torch.cuda.stream(side):
+            out = fn()
+            ev = torch.cuda.Event()
+            ev.record(side)
+        main.wait_event(ev)
+        out.record_stream(main)
+        return out
 
     @classmethod
     def _at_end_of_backward(cls) -> None:
