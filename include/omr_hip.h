@@ -290,6 +290,13 @@ typedef struct omr_decode_linear_args {
 int omr_decode_linear(const omr_decode_linear_args* args, void* stream);
 int omr_decode_steps(const omr_decode_desc* desc, long* tokens, int t0, int n_steps, long* out_tokens, float* out_top1, float* last_logits,
                      void* stream);
+/* Weighted late fusion (src/multimodal/weighted_multimodal/test.py:21-70) without a host round trip per token: positions
+ * t0 .. t0+n_steps-1 of TWO models (descriptors with B = 1 and the same vocabulary) in lock-step; per position
+ * argmax(alpha * softmax(logits_a) + (1 - alpha) * softmax(logits_b)) (omr_weighted_argmax) is written to out_tokens[s]
+ * (and its mixed probability to out_prob[s], nullable) and fed to both models' next position through `tokens` (device,
+ * 1 entry: in = the token of position t0).  logits_a / logits_b: fp32 scratch of ldv entries each. */
+int omr_weighted_decode_steps(const omr_decode_desc* desc_a, const omr_decode_desc* desc_b, float alpha, long* tokens, int t0, int n_steps,
+                              long* out_tokens, float* out_prob, float* logits_a, float* logits_b, void* stream);
 
 /* ---- loss ------------------------------------------------------------------------------------------------ */
 /* CrossEntropyLoss(ignore_index=pad) (model.py:109,166) on row-major logits [M][ldv]; acc2 = {sum, count} (fp64). */

@@ -410,3 +410,20 @@ extern "C" int omr_decode_steps(const omr_decode_desc* dp, long* tokens, int t0,
     }
     return OMR_OK;
 }
+
+/* Weighted late fusion (src/multimodal/weighted_multimodal/test.py:21-70) as ONE host call per run of tokens: two unimodal
+ * models with their own KV caches decode the same prefix in lock-step; per position both descriptors run their step
+ * (omr_decode_steps without a pick: fp32 logits only), omr_weighted_argmax mixes the two softmaxes and picks, and the token
+ * reaches BOTH models' next position through device memory.  bs = 1 like the reference (test.py:27). */
+extern "C" int omr_weighted_decode_steps(const omr_decode_desc* da, const omr_decode_desc* db, float alpha, long* tokens, int t0, int n_steps,
+                                         long* out_tokens, float* out_prob, float* logits_a, float* logits_b, void* stream) {
+    if (!da || !db || !tokens || !out_tokens || !logits_a || !logits_b || n_steps < 1 || t0 < 0) return OMR_ERR_ARG;
+    if (da->B != 1 || db->B != 1 || da->V != db->V) return OMR_ERR_ARG;
+    for (int s = 0; s < n_steps; ++s) {
+        TRY(omr_decode_steps(da, tokens, t0 + s, 1, nullptr, nullptr, logits_a, stream));
+        TRY(omr_decode_steps(db, tokens, t0 + s, 1, nullptr, nullptr, logits_b, stream));
+        TRY(omr_weighted_argmax(logits_a, logits_b, da->V, alpha, out_tokens + s, out_prob ? out_prob + s : nullptr, stream));
+        if (hipMemcpyAsync(tokens, out_tokens + s, sizeof(long), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return OMR_ERR_LAUNCH;
+    }
+    return OMR_OK;
+}
