@@ -278,7 +278,11 @@ long omr_decode_workspace_bytes(const omr_decode_desc* desc);
  * amax_idx (nullable): also return, per row, the first index of the largest rounded output and its value (the greedy pick of
  * model.py:187,253): every workgroup leaves its 16-column candidate in amax_part (>= 2 * M * ceil(N/16) floats of scratch) and
  * a second, one-wave-per-row launch reduces them -- cheaper than a pass over the N logits.
- * Requires K a multiple of 128 (bf16) / 64 (fp32) columns, K <= 2048, 16-byte aligned weight rows. */
+ * w8 (nullable; BASELINE config 5 "fp8 MFMA weights", an extension): the weight rows as OCP e4m3 codes [N][K] with one fp32
+ * scale per output row (omr_quantize_rows_fp8 of the matrix); the codes are dequantised as they are loaded -- half the weight
+ * bytes of a bf16 row, the dominant traffic of a decode position -- the products are summed in fp32 against the same input
+ * rows and the row scale multiplies the finished sum.  `w` is then unused.
+ * Requires K a multiple of 128 (bf16 / fp8 weights) / 64 (fp32) columns, K <= 2048, 16-byte aligned weight rows. */
 typedef struct omr_decode_linear_args {
     int dtype, pro, M, N, K, relu, n0, nsplit, H, hd, vocab, pad_;
     float eps, pad2_;
@@ -286,6 +290,7 @@ typedef struct omr_decode_linear_args {
     const long* tokens; const void* emb; const float* pe_row; const float* part;
     const void* w; const float* bias; void* out0; long ld0; void* out1; long ld1; float* out32; long ld32;
     long* amax_idx; float* amax_val; float* amax_part;
+    const unsigned char* w8; const float* w8_scale;
 } omr_decode_linear_args;
 int omr_decode_linear(const omr_decode_linear_args* args, void* stream);
 int omr_decode_steps(const omr_decode_desc* desc, long* tokens, int t0, int n_steps, long* out_tokens, float* out_top1, float* last_logits,

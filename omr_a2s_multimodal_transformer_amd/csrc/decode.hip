@@ -66,23 +66,42 @@ __device__ __forceinline__ float klane_sum(float v) {
     return v;
 }
 
-template <typename T>
+// e4m3 (OCP) weight chunk -> fp32: 8 codes per lane and chunk (gfx950 converts two codes per v_cvt_pk_f32_fp8)
+struct W8Chunk { uint2 v; };
+__device__ __forceinline__ void w_unpack(const W8Chunk& c, float (&f)[8]) {
+    const auto p0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.v.x, false), p1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.v.x, true);
+    const auto p2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.v.y, false), p3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c.v.y, true);
+    f[0] = p0[0]; f[1] = p0[1]; f[2] = p1[0]; f[3] = p1[1]; f[4] = p2[0]; f[5] = p2[1]; f[6] = p3[0]; f[7] = p3[1];
+}
+__device__ __forceinline__ void w_unpack(const bf16x8& c, float (&f)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = to_f32(c[e]);
+}
+__device__ __forceinline__ void w_unpack(const f32x4& c, float (&f)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = c[e];
+}
+
+template <typename T, bool W8>
 __global__ __launch_bounds__(256) void decode_linear_kernel(omr_decode_linear_args a) {
     typedef typename Frag<T>::type F;
-    constexpr int VEC = Frag<T>::N;
+    constexpr int VEC = W8 ? 8 : Frag<T>::N;                            // weight elements per chunk (fp8: 8 codes = 8 bytes)
+    typedef typename std::conditional<W8, W8Chunk, F>::type WF;
     extern __shared__ __attribute__((aligned(16))) float xs[];          // [RM][K]: the rows as the GEMM sees them (values rounded to T)
     __shared__ float mls[4 * 2 * MAXHS];                                 // prologue 3: per-wave (max | sum) strips
     __shared__ float cand[RM][NOUT];                                     // greedy pick: the workgroup's rounded outputs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = tid / KL, kl = tid % KL;
     const int n = blockIdx.x * NOUT + nl, K = a.K, nch = K / VEC;
-    const T* wrow = (const T*)a.w + (long)(n < a.N ? n : 0) * K;
+    typedef typename std::conditional<W8, unsigned char, T>::type WT;
+    const WT* wrow = (W8 ? (const WT*)a.w8 : (const WT*)a.w) + (long)(n < a.N ? n : 0) * K;
+
     // K is a multiple of KL * VEC (host check): chunk kl + i * KL exists for every lane or for none, so the loops over a thread's
     // chunks have block-uniform bounds and the loads carry no per-lane test (columns past N read row 0 and are never stored)
     const int cpt = nch / KL;
-    F wv[WCH];
+    WF wv[WCH];
 #pragma unroll
     for (int i = 0; i < WCH; ++i)
-        if (i < cpt) wv[i] = *reinterpret_cast<const F*>(wrow + (kl + i * KL) * VEC);
+        if (i < cpt) wv[i] = *reinterpret_cast<const WF*>(wrow + (kl + i * KL) * VEC);
     const int per = K / 64;                                              // prologues 1-3: a wave builds a row, lane = `per` consecutive columns
     {
         const int r0 = blockIdx.y * RM, rm = min(RM, a.M - r0);
@@ -164,18 +183,22 @@ __global__ __launch_bounds__(256) void decode_linear_kernel(omr_decode_linear_ar
             for (int i = 0; i < WCH; ++i)
                 if (i < cpt) {
                     const float* xc = xs + (kl + i * KL) * VEC;
+                    float wf[VEC];
+                    w_unpack(wv[i], wf);
 #pragma unroll
                     for (int r = 0; r < NR; ++r)
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) acc[r] = fmaf(to_f32(wv[i][e]), xc[r * K + e], acc[r]);
+                        for (int e = 0; e < VEC; ++e) acc[r] = fmaf(wf[e], xc[r * K + e], acc[r]);
                 }
             for (int i = WCH; i < cpt; ++i) {                            // K beyond the prefetched chunks
-                const F wx = *reinterpret_cast<const F*>(wrow + (kl + i * KL) * VEC);
+                const WF wx = *reinterpret_cast<const WF*>(wrow + (kl + i * KL) * VEC);
                 const float* xc = xs + (kl + i * KL) * VEC;
+                float wf[VEC];
+                w_unpack(wx, wf);
 #pragma unroll
                 for (int r = 0; r < NR; ++r)
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[r] = fmaf(to_f32(wx[e]), xc[r * K + e], acc[r]);
+                    for (int e = 0; e < VEC; ++e) acc[r] = fmaf(wf[e], xc[r * K + e], acc[r]);
             }
 #pragma unroll
             for (int r = 0; r < NR; ++r) acc[r] = klane_sum(acc[r]);
@@ -183,11 +206,11 @@ __global__ __launch_bounds__(256) void decode_linear_kernel(omr_decode_linear_ar
         if (rm == 1) slice_rows(std::integral_constant<int, 1>());
         else slice_rows(std::integral_constant<int, RM>());             // rows past rm: arithmetic on stale LDS, never stored
         if (kl == 0 && n < a.N) {
-            const float bv = a.bias ? a.bias[n] : 0.f;
+            const float bv = a.bias ? a.bias[n] : 0.f, wsc = W8 ? a.w8_scale[n] : 1.f;
 #pragma unroll
             for (int r = 0; r < RM; ++r) {
                 if (r >= rm) break;
-                float v = acc[r] + bv;
+                float v = W8 ? fmaf(acc[r], wsc, bv) : acc[r] + bv;
                 if (a.relu) v = fmaxf(v, 0.f);
                 const T o = from_f32<T>(v);
                 const long m = r0 + r;
@@ -240,9 +263,10 @@ __global__ __launch_bounds__(64) void decode_pick_kernel(const float* __restrict
 extern "C" int omr_decode_linear(const omr_decode_linear_args* ap, void* stream) {
     if (!ap) return OMR_ERR_ARG;
     const omr_decode_linear_args& a = *ap;
-    const int vec = a.dtype == OMR_BF16 ? 8 : 4;
-    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % vec || a.K > 2048 || !a.w || !a.out0 || a.n0 < 0) return OMR_ERR_ARG;
-    if (((uintptr_t)a.w & 15) || (a.n0 < a.N && !a.out1)) return OMR_ERR_ARG;
+    const int vec = (a.dtype == OMR_BF16 || a.w8) ? 8 : 4;
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % vec || a.K > 2048 || (!a.w && !a.w8) || !a.out0 || a.n0 < 0) return OMR_ERR_ARG;
+    if (a.w8 ? (!a.w8_scale || ((uintptr_t)a.w8 & 7)) : (((uintptr_t)a.w & 15) != 0)) return OMR_ERR_ARG;
+    if (a.n0 < a.N && !a.out1) return OMR_ERR_ARG;
     if (a.pro < 0 || a.pro > 3) return OMR_ERR_ARG;
     if (a.K % (KL * vec)) return OMR_ERR_UNSUPPORTED;                    // whole 16-lane chunk groups (128 bf16 / 64 fp32 columns)
     if (a.amax_idx && !a.amax_part) return OMR_ERR_ARG;
@@ -254,8 +278,10 @@ extern "C" int omr_decode_linear(const omr_decode_linear_args* ap, void* stream)
     if (a.pro == 3 && (!a.part || a.nsplit < 1 || a.nsplit > MAXSPLIT || a.H < 1 || a.hd < 1 || a.H * a.hd != a.K || a.H * a.nsplit > MAXHS || a.hd % (a.K / 64))) return OMR_ERR_ARG;
     const dim3 grid((unsigned)cdiv(a.N, NOUT), (unsigned)cdiv(a.M, RM)), block(256);
     const size_t shm = (size_t)RM * a.K * sizeof(float);
-    if (a.dtype == OMR_BF16) hipLaunchKernelGGL((decode_linear_kernel<bf16>), grid, block, shm, (hipStream_t)stream, a);
-    else if (a.dtype == OMR_F32) hipLaunchKernelGGL((decode_linear_kernel<float>), grid, block, shm, (hipStream_t)stream, a);
+    if (a.dtype == OMR_BF16 && a.w8) hipLaunchKernelGGL((decode_linear_kernel<bf16, true>), grid, block, shm, (hipStream_t)stream, a);
+    else if (a.dtype == OMR_F32 && a.w8) hipLaunchKernelGGL((decode_linear_kernel<float, true>), grid, block, shm, (hipStream_t)stream, a);
+    else if (a.dtype == OMR_BF16) hipLaunchKernelGGL((decode_linear_kernel<bf16, false>), grid, block, shm, (hipStream_t)stream, a);
+    else if (a.dtype == OMR_F32) hipLaunchKernelGGL((decode_linear_kernel<float, false>), grid, block, shm, (hipStream_t)stream, a);
     else return OMR_ERR_UNSUPPORTED;
     if (a.amax_idx) hipLaunchKernelGGL(decode_pick_kernel, dim3((unsigned)a.M), dim3(64), 0, (hipStream_t)stream, a.amax_part, (int)grid.x, a.amax_idx, a.amax_val);
     OMR_CHECK_LAUNCH();
@@ -293,12 +319,12 @@ extern "C" int omr_decode_steps(const omr_decode_desc* dp, long* tokens, int t0,
         if (rc != OMR_OK) return rc;
         return omr_gemm_fp8(dt, B, N, K, w.a8, (K + 15) / 16 * 16, w.sa8, W8[mat] + (size_t)row0 * K, K, S8[mat] + row0, c, ldc, bias, relu, stream);
     };
-    // ---- bf16 / fp32: 8 launches per layer.  Every element-wise step between two linears (embedding + positional row, the
+    // ---- 8 launches per layer (bf16 / fp32 weights, or e4m3 weights dequantised on load by the row kernel).  Every element-wise step between two linears (embedding + positional row, the
     // three add + LayerNorm, the merge of the key-split attention) is folded into the loading of the NEXT linear's input rows
     // (omr_decode_linear prologues); the residual stream alternates between two buffers because the workgroup that stores a
     // freshly normalised row runs beside workgroups still reading the previous one.
     const int smax = d.S > d.max_len ? d.S : d.max_len, splits_max = (smax + 255) / 256 < MAXSPLIT ? (smax + 255) / 256 : MAXSPLIT;
-    if (!d.fp8 && (dm == 128 || dm == 256 || dm == 512) && d.ff <= 2048 && d.ff % (16 * (dt == OMR_BF16 ? 8 : 4)) == 0 && d.nhead * splits_max <= MAXHS) {
+    if ((dm == 128 || dm == 256 || dm == 512) && d.ff <= 2048 && d.ff % (16 * ((dt == OMR_BF16 || d.fp8) ? 8 : 4)) == 0 && d.nhead * splits_max <= MAXHS) {
         const long* tok_in = tokens;
         for (int s = 0; s < n_steps; ++s) {
             const int t = t0 + s;
@@ -306,8 +332,10 @@ extern "C" int omr_decode_steps(const omr_decode_desc* dp, long* tokens, int t0,
             char* xa = w.x; char* xb = w.x2;                                        // xa: residual stream entering the sub-layer
             auto lin = [&](int pro, const void* x, const void* res, const float* g, const float* bt, void* xn_out, const float* part, int nsplit,
                            const void* wmat, const float* bias, int N, int K, int relu, void* out0, long ld0, int n0, void* out1, long ld1,
-                           float* out32, long* amax_idx = nullptr, float* amax_val = nullptr) -> int {
+                           float* out32, long* amax_idx = nullptr, float* amax_val = nullptr, const unsigned char* w8 = nullptr,
+                           const float* s8 = nullptr) -> int {
                 omr_decode_linear_args a = {};
+                a.w8 = d.fp8 ? w8 : nullptr; a.w8_scale = d.fp8 ? s8 : nullptr;
                 a.amax_idx = amax_idx; a.amax_val = amax_val; a.amax_part = amax_idx ? w.apart : nullptr;
                 a.dtype = dt; a.pro = pro; a.M = B; a.N = N; a.K = K; a.relu = relu; a.n0 = n0; a.nsplit = nsplit; a.H = d.nhead; a.hd = hd; a.vocab = d.V;
                 a.eps = 1e-5f; a.x = x; a.ldx = K; a.res = res; a.ldres = K; a.gamma = g; a.beta = bt; a.xn_out = xn_out;
@@ -318,29 +346,31 @@ extern "C" int omr_decode_steps(const omr_decode_desc* dp, long* tokens, int t0,
             const float *pg = nullptr, *pb = nullptr;                               // norm3 of the previous layer, still to be applied
             for (int l = 0; l < d.L; ++l) {
                 const void* const* Wl = d.layer_w + (size_t)l * OMR_DECODE_LAYER_PTRS;
+                const unsigned char* const* W8l = d.fp8 ? d.layer_w8 + (size_t)l * OMR_DECODE_LAYER_FP8 : nullptr;     // e4m3 rows + row scales of the
+                const float* const* S8l = d.fp8 ? d.layer_s8 + (size_t)l * OMR_DECODE_LAYER_FP8 : nullptr;             // layer's six matrices
                 char* cache_l = (char*)d.self_kv + ((size_t)l * B * d.max_len) * 2 * dm * es;
                 char* kv_row = cache_l + (size_t)t * 2 * dm * es;
                 // q | k|v projection of the position: q -> w.q, k|v straight into row t of the cache.  Its input is the
                 // embedding (layer 0) or norm3(x + ffn) of the previous layer; either way the rows land in xb
-                if (l == 0) TRY(lin(2, nullptr, nullptr, nullptr, nullptr, xb, nullptr, 0, Wl[0], (const float*)Wl[1], 3 * dm, dm, 0, w.q, dm, dm, kv_row, (long)d.max_len * 2 * dm, nullptr));
-                else TRY(lin(1, w.proj, xa, pg, pb, xb, nullptr, 0, Wl[0], (const float*)Wl[1], 3 * dm, dm, 0, w.q, dm, dm, kv_row, (long)d.max_len * 2 * dm, nullptr));
+                if (l == 0) TRY(lin(2, nullptr, nullptr, nullptr, nullptr, xb, nullptr, 0, Wl[0], (const float*)Wl[1], 3 * dm, dm, 0, w.q, dm, dm, kv_row, (long)d.max_len * 2 * dm, nullptr, nullptr, nullptr, W8l ? W8l[0] : nullptr, S8l ? S8l[0] : nullptr));
+                else TRY(lin(1, w.proj, xa, pg, pb, xb, nullptr, 0, Wl[0], (const float*)Wl[1], 3 * dm, dm, 0, w.q, dm, dm, kv_row, (long)d.max_len * 2 * dm, nullptr, nullptr, nullptr, W8l ? W8l[0] : nullptr, S8l ? S8l[0] : nullptr));
                 { char* tsw = xa; xa = xb; xb = tsw; }
                 const char* k0 = cache_l + (size_t)lo * 2 * dm * es;
                 int ns = 1;
                 TRY(omr_attn_fwd_split_partials(dt, w.q, k0, k0 + (size_t)dm * es, w.o, w.lse, dm, 2 * dm, 2 * dm, dm, dm, (long)d.max_len * 2 * dm,
                                                 (long)d.max_len * 2 * dm, dm, B, d.nhead, 1, t + 1 - lo, hd, w.split, w.split_floats, &ns, stream));
-                TRY(lin(ns > 1 ? 3 : 0, w.o, nullptr, nullptr, nullptr, nullptr, w.split, ns, Wl[2], (const float*)Wl[3], dm, dm, 0, w.proj, dm, dm, nullptr, 0, nullptr));
+                TRY(lin(ns > 1 ? 3 : 0, w.o, nullptr, nullptr, nullptr, nullptr, w.split, ns, Wl[2], (const float*)Wl[3], dm, dm, 0, w.proj, dm, dm, nullptr, 0, nullptr, nullptr, nullptr, W8l ? W8l[1] : nullptr, S8l ? S8l[1] : nullptr));
                 // cross-attention query from norm1(x + self-attention)
-                TRY(lin(1, w.proj, xa, (const float*)Wl[4], (const float*)Wl[5], xb, nullptr, 0, Wl[6], (const float*)Wl[7], dm, dm, 0, w.q, dm, dm, nullptr, 0, nullptr));
+                TRY(lin(1, w.proj, xa, (const float*)Wl[4], (const float*)Wl[5], xb, nullptr, 0, Wl[6], (const float*)Wl[7], dm, dm, 0, w.q, dm, dm, nullptr, 0, nullptr, nullptr, nullptr, W8l ? W8l[2] : nullptr, S8l ? S8l[2] : nullptr));
                 { char* tsw = xa; xa = xb; xb = tsw; }
                 const char* ck = (const char*)d.cross_kv + (size_t)l * 2 * dm * es;
                 TRY(omr_attn_fwd_split_partials(dt, w.q, ck, ck + (size_t)dm * es, w.o, w.lse, dm, d.cross_ld, d.cross_ld, dm, dm, d.cross_bs, d.cross_bs, dm,
                                                 B, d.nhead, 1, d.S, hd, w.split, w.split_floats, &ns, stream));
-                TRY(lin(ns > 1 ? 3 : 0, w.o, nullptr, nullptr, nullptr, nullptr, w.split, ns, Wl[8], (const float*)Wl[9], dm, dm, 0, w.proj, dm, dm, nullptr, 0, nullptr));
+                TRY(lin(ns > 1 ? 3 : 0, w.o, nullptr, nullptr, nullptr, nullptr, w.split, ns, Wl[8], (const float*)Wl[9], dm, dm, 0, w.proj, dm, dm, nullptr, 0, nullptr, nullptr, nullptr, W8l ? W8l[3] : nullptr, S8l ? S8l[3] : nullptr));
                 // feed-forward from norm2(x + cross-attention)
-                TRY(lin(1, w.proj, xa, (const float*)Wl[10], (const float*)Wl[11], xb, nullptr, 0, Wl[12], (const float*)Wl[13], d.ff, dm, 1, w.h, d.ff, d.ff, nullptr, 0, nullptr));
+                TRY(lin(1, w.proj, xa, (const float*)Wl[10], (const float*)Wl[11], xb, nullptr, 0, Wl[12], (const float*)Wl[13], d.ff, dm, 1, w.h, d.ff, d.ff, nullptr, 0, nullptr, nullptr, nullptr, W8l ? W8l[4] : nullptr, S8l ? S8l[4] : nullptr));
                 { char* tsw = xa; xa = xb; xb = tsw; }
-                TRY(lin(0, w.h, nullptr, nullptr, nullptr, nullptr, nullptr, 0, Wl[14], (const float*)Wl[15], dm, d.ff, 0, w.proj, dm, dm, nullptr, 0, nullptr));
+                TRY(lin(0, w.h, nullptr, nullptr, nullptr, nullptr, nullptr, 0, Wl[14], (const float*)Wl[15], dm, d.ff, 0, w.proj, dm, dm, nullptr, 0, nullptr, nullptr, nullptr, W8l ? W8l[5] : nullptr, S8l ? S8l[5] : nullptr));
                 pg = (const float*)Wl[16]; pb = (const float*)Wl[17];
             }
             // vocabulary head (Conv1d k=1, decoder.py:145-146) on norm3 of the last layer: logits rounded to the compute dtype like
@@ -348,7 +378,7 @@ extern "C" int omr_decode_steps(const omr_decode_desc* dp, long* tokens, int t0,
             // ... and the greedy pick (model.py:187,253): candidates from the head's workgroups, one small launch to reduce them; the
             // next position reads the token from where it was written
             TRY(lin(1, w.proj, xa, pg, pb, xb, nullptr, 0, d.head_w, d.head_b, d.V, dm, 0, w.logits, d.ldv, d.V, nullptr, 0, w.logits32,
-                    out_tokens ? out_tokens + (size_t)s * B : nullptr, (out_tokens && out_top1) ? out_top1 + (size_t)s * B : nullptr));
+                    out_tokens ? out_tokens + (size_t)s * B : nullptr, (out_tokens && out_top1) ? out_top1 + (size_t)s * B : nullptr, d.head_w8, d.head_s8));
             if (out_tokens) tok_in = out_tokens + (size_t)s * B;
         }
         if (out_tokens && hipMemcpyAsync(tokens, out_tokens + (size_t)(n_steps - 1) * B, (size_t)B * sizeof(long), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
@@ -357,7 +387,8 @@ extern "C" int omr_decode_steps(const omr_decode_desc* dp, long* tokens, int t0,
             return OMR_ERR_LAUNCH;
         return OMR_OK;
     }
-    // ---- fp8 weights (and model widths the row kernel does not take): one GEMM / element-wise kernel per step of the layer
+    // ---- model widths the row kernel does not take: one GEMM / element-wise kernel per step of the layer (fp8 mode: activations
+    //      quantised per token, fp8 MFMA GEMM)
     for (int s = 0; s < n_steps; ++s) {
         const int t = t0 + s;
         // embedding(tgt) + pe[t]  (decoder.py:124; T_len = 1 so every row of the batch takes the table row given)

@@ -86,7 +86,8 @@ class _DecodeLinearArgs(ctypes.Structure):
                 ("tokens", ctypes.c_void_p), ("emb", ctypes.c_void_p), ("pe_row", ctypes.c_void_p), ("part", ctypes.c_void_p),
                 ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("out0", ctypes.c_void_p), ("ld0", ctypes.c_long),
                 ("out1", ctypes.c_void_p), ("ld1", ctypes.c_long), ("out32", ctypes.c_void_p), ("ld32", ctypes.c_long),
-                ("amax_idx", ctypes.c_void_p), ("amax_val", ctypes.c_void_p), ("amax_part", ctypes.c_void_p)]
+                ("amax_idx", ctypes.c_void_p), ("amax_val", ctypes.c_void_p), ("amax_part", ctypes.c_void_p),
+                ("w8", ctypes.c_void_p), ("w8_scale", ctypes.c_void_p)]
 
 
 def decode_linear(w: Tensor, bias: Optional[Tensor], *, x: Optional[Tensor] = None, res: Optional[Tensor] = None, ln=None, tokens: Optional[Tensor] = None,
