@@ -77,6 +77,11 @@ int omr_image_vpass_to_float(const unsigned char* src, int h, int w, const int* 
  * LocalAlignment (package absent here: PARITY UNPINNED).  ref / query: token ids; ops receives one of 'm' 'i' 'd' per
  * alignment column (capacity nr + nq), r_pos / q_pos the 0-based start of the aligned region in ref / query; returns the
  * number of columns. */
+/* Token noise of Transformer.apply_teacher_forcing (model.py:152-160) in one HOST call, continuing Python's own Mersenne
+ * Twister: for each of `count` tokens (row-major B x T) draw random.random(); if it is < prob and the token is not pad_idx,
+ * replace it by random.randint(0, vocab - 1).  mt_state[624] / *mt_index = random.getstate()[1] (words, position); both are
+ * advanced exactly as the interpreter's calls would advance them, for random.setstate().  Host memory only. */
+int omr_teacher_forcing_noise(long* tokens, long count, double prob, long pad_idx, long vocab, unsigned int* mt_state, int* mt_index);
 int omr_sw_align(const int* ref, int nr, const int* query, int nq, int match, int mismatch, int gap_penalty,
                  int gap_extension_penalty, char* ops, int* r_pos, int* q_pos, int* score);
 /* beam-search expansion (BASELINE config C5; an extension: the reference decodes greedily): per row the k largest

@@ -4,6 +4,7 @@ for the parameterised builds BASELINE.json names.  The three reference quirks (S
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import random
 from typing import Dict, List, Optional, Tuple
@@ -13,6 +14,7 @@ import torch.nn as nn
 
 from . import functional as Fn
 from . import kernels as K
+from ._lib import lib
 from .config import ModelConfig
 from .decoder import Decoder, MultiheadAttention
 from .encoder import HEIGHT_REDUCTION, WIDTH_REDUCTION, Encoder
@@ -312,13 +314,16 @@ class Transformer(_Base):
     def apply_teacher_forcing(self, y: torch.Tensor) -> torch.Tensor:
         """model.py:152-160: each non-pad token is replaced w.p. teacher_forcing_prob by randint(0, V-1) drawn
         from Python's `random` in row-major order (same draw sequence as the reference's double loop)."""
-        rows = y.detach().cpu().tolist()            # plain Python lists: no tensor indexing inside the B x T loop
-        V, p, pad, rnd, rint = len(self.w2i), self.teacher_forcing_prob, self.padding_idx, random.random, random.randint
-        for row in rows:
-            for j, tok in enumerate(row):
-                if rnd() < p and tok != pad:        # same short-circuit as the reference: randint is drawn only for replaced tokens
-                    row[j] = rint(0, V - 1)
-        out = torch.tensor(rows, dtype=y.dtype)
+        out = y.detach().to("cpu", torch.int64).contiguous().clone()
+        # The B x T double loop runs in C on the interpreter's OWN generator state (omr_teacher_forcing_noise: the calls
+        # CPython's random.random / random.randint would make, in the reference's order), 1.8 ms -> 0.2 ms per C2 step.
+        version, internal, gauss = random.getstate()
+        state = (ctypes.c_uint * 624)(*internal[:624])
+        index = ctypes.c_int(internal[624])
+        lib().call("omr_teacher_forcing_noise", out.data_ptr(), out.numel(), float(self.teacher_forcing_prob), int(self.padding_idx), len(self.w2i),
+                   ctypes.cast(state, ctypes.c_void_p), ctypes.byref(index))
+        random.setstate((version, tuple(state) + (index.value,), gauss))
+        out = out.to(y.dtype)
         return out.pin_memory() if (not y.is_cuda and torch.cuda.is_available()) else out.to(y.device)
 
     def training_step(self, batch, batch_idx) -> torch.Tensor:

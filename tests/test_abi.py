@@ -26,7 +26,7 @@ def test_every_exported_entry_point_is_declared_in_the_header():
     from omr_a2s_multimodal_transformer_amd.decoder import _DecodeDesc
     from omr_a2s_multimodal_transformer_amd.kernels import _DecodeLinearArgs, _DwProblem
     assert ctypes.sizeof(_DecodeDesc) == 12 * 4 + 11 * 8 + 4 * 8 and ctypes.sizeof(_DwProblem) == 80
-    assert ctypes.sizeof(_DecodeLinearArgs) == 12 * 4 + 2 * 4 + 22 * 8
+    assert ctypes.sizeof(_DecodeLinearArgs) == 12 * 4 + 2 * 4 + 24 * 8        # + w8, w8_scale (round 3)
 
 
 def test_argument_types_follow_the_header():
