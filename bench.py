@@ -186,6 +186,7 @@ def main():
 
     if rank == 0 and not args.no_roofline and args.config == "c2":
         out["roofline"] = roofline_dominant_kernel(B, c["img"][0], c["img"][1], c["dtype"])
+        out["roofline"]["others"] = roofline_others(B, c["img"][0], c["img"][1], T, c["d"], 4)
     if rank == 0 and not args.no_roofline and x1 is not None:
         out["decode"] = decode_rate(model, x1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -334,6 +335,71 @@ def roofline_dominant_kernel(B, H, W, dtype):
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
             "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": nbytes,
             "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1), "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)}
+
+
+def _timed(fn, n=12, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def roofline_others(B, H, W, T, d, nhead):
+    """The other large kernels of a C2 step by time (profiles/r03_c2_families_*.txt), each against the roofline that bounds it,
+    timed live at the step's own shapes (HIP events on the launch stream; the library launches on torch's current stream):
+    cross-attention forward / backward (one decoder layer's: B x 4 heads x 512 queries x 4096 memory keys, dropout + key bias as
+    in training; MFMA-eligible work 4*T*S*d*B flops forward, 2.5x that backward), InstanceNorm backward apply on the largest map
+    (32 channels at full resolution: 2 reads + 1 write), the 64-channel conv weight gradient (conv_blocks.2.conv2: 18*64*64 flops
+    per pixel; also 2 tensor reads)."""
+    from omr_a2s_multimodal_transformer_amd import kernels as K
+    dev, bf = torch.device("cuda"), torch.bfloat16
+    S = tokens_of((H, W))
+    res = []
+    q = torch.randn(B, T, d, device=dev, dtype=bf)
+    kv = torch.randn(B, S, 2 * d, device=dev, dtype=bf)
+    k, v = kv[..., :d], kv[..., d:]
+    kb = torch.zeros(B, S, device=dev)
+    words = K.attn_dropout_words(B, nhead, T, S, 0.1, 7, dev)
+    kw = dict(key_bias=kb, dropout_p=0.1, seed=7, drop_words=words)
+    o, lse = K.attn_fwd(q, k, v, nhead, **kw)
+    do, dq, dkv = torch.randn_like(o), torch.empty_like(q), torch.empty_like(kv)
+    fl = 4.0 * B * T * S * d
+    ms = _timed(lambda: K.attn_fwd(q, k, v, nhead, **kw))
+    res.append({"kernel": "attn_fwd_kernel (cross-attention of one decoder layer, dropout 0.1 + key bias)", "bound": "mfma", "avg_launch_ms": round(ms, 4),
+                "algorithmic_flops": fl, "achieved": round(fl / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / MFMA_BF16_PEAK_TF, 4)})
+    ms = _timed(lambda: K.attn_bwd(q, k, v, o, do, lse, dq, dkv[..., :d], dkv[..., d:], nhead, **kw))
+    res.append({"kernel": "attn_delta + attn_bwd_dq + attn_bwd_dkv (the same layer's backward)", "bound": "mfma", "avg_launch_ms": round(ms, 4),
+                "algorithmic_flops": 2.5 * fl, "achieved": round(2.5 * fl / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(2.5 * fl / ms / 1e9 / MFMA_BF16_PEAK_TF, 4)})
+    del q, kv, o, do, dq, dkv, words
+    C = 32
+    x = torch.rand((B, H, W, C), device=dev).to(bf)
+    g = torch.rand((B, H, W, C), device=dev).to(bf)
+    mean, rstd = K.instnorm_stats(x)
+    ws, slots = K.conv_stat_ws(B, H, W, C, dev)
+    ws.zero_()
+    ms = _timed(lambda: K.instnorm_bwd_apply(g, x, mean, rstd, ws, slots, relu_mask=True, relu_scale=1.0))
+    nb = 3.0 * B * H * W * C * 2
+    res.append({"kernel": "instnorm_bwd_apply_kernel (conv_blocks.1: 32 channels at full resolution)", "bound": "hbm", "avg_launch_ms": round(ms, 4),
+                "algorithmic_bytes": nb, "achieved": round(nb / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb / ms / 1e6 / HBM_PEAK_GBS, 4)})
+    del x, g
+    C, h2, w2 = 64, H // 2, W // 2
+    x = torch.rand((B, h2, w2, C), device=dev).to(bf)
+    dy = torch.rand((B, h2, w2, C), device=dev).to(bf)
+    dw = torch.zeros((C, 3, 3, C), device=dev)
+    db = torch.zeros(C, device=dev)
+    ms = _timed(lambda: K.conv3x3_wgrad(x, dy, dw, db=db))
+    fl = 18.0 * C * C * B * h2 * w2
+    res.append({"kernel": "wgrad_dma_kernel<64,64> (conv_blocks.2.conv2 weight gradient: 64 -> 64 channels at 128x1024)", "bound": "mfma", "avg_launch_ms": round(ms, 4),
+                "algorithmic_flops": fl, "algorithmic_bytes": 2.0 * B * h2 * w2 * C * 2, "achieved": round(fl / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TF,
+                "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / MFMA_BF16_PEAK_TF, 4)})
+    return res
 
 
 def usable_cores():
