@@ -325,7 +325,7 @@ def roofline_dominant_kernel(B, H, W, dtype):
     gbs = nbytes / (ms * 1e-3) / 1e9
     traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same launch (profiles/)
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_dominant_kernel_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_dominant_kernel_pmc.json")) as f:
             if (B, H, W, dtype) == (32, 256, 2048, "bf16"):
                 traffic = json.load(f)["hbm_bytes_per_launch"]
     except Exception:
