@@ -65,6 +65,8 @@ __device__ __forceinline__ void mma32(f32x16& acc, u8x16 a, u8x16 b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a2[1], b2[1], acc, 0, 0, 0);
 }
 
+int omr_gemm_panel_bf16(const GemmArgs& g, hipStream_t s);      // gemm_panel.hip
+
 namespace {
 
 // physical - logical row offset of the tile that starts at logical row i (tiles never straddle a group: host-checked)
@@ -462,6 +464,12 @@ extern "C" int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, i
     g.ksplit_len = len;
     int splits = cdiv(K, len);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == OMR_BF16 && c_dtype == OMR_BF16 && !transA && !transB && !relu && !accumulate && splits == 1 && !colsum_a && drop_p == 0.f &&
+        !(lda % 8) && !(ldb % 8)) {
+        // tall-and-wide output with a short reduction (the all-layer K|V projection of the memory): panel kernel, gemm_panel.hip
+        const int rc = omr_gemm_panel_bf16(g, s);
+        if (rc != OMR_ERR_UNSUPPORTED) return rc;
+    }
     if (dtype == OMR_BF16) {
         if (c_dtype == OMR_BF16) return launch<bf16, bf16>(g, transA, transB, splits, s);
         return launch<bf16, float>(g, transA, transB, splits, s);

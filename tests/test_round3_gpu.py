@@ -243,3 +243,35 @@ def test_c5_composition_multimodal_memory_beam_search_fp8():
     assert m.decoder.init_decode(mem).fp8
     assert b1 == greedy
     assert np.isfinite(s1) and np.isfinite(s4) and s4 >= s1 - 1e-4 and len(b4) >= 1
+
+
+# ------------------------------------------------------------------------------------------------ panel GEMM (all-layer K|V projection)
+
+@pytest.mark.parametrize("M,N,Kd,grouped", [(51200 + 77, 1024, 256, False), (65536, 3072, 256, True), (51200, 512, 128, False)])
+def test_panel_gemm_matches_fp64_product(M, N, Kd, grouped):
+    """omr_gemm routes tall-and-wide bf16 products with K = 128 / 256 (the K|V projection of the memory for all decoder layers,
+    FusedCrossKVFn) to gemm_panel.hip: against the fp64 product of the same bf16 operands, incl. the row-group view of the packed
+    in_proj matrices ([Wq;Wk;Wv] blocks: K|V rows of layer l at physical rows 3d*l + d ..) and a ragged M."""
+    from omr_a2s_multimodal_transformer_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    a = (torch.randn((M, Kd), generator=g) * 0.7).to(torch.bfloat16)
+    if grouped:
+        d = Kd
+        L = N // (2 * d)
+        w_phys = (torch.randn((L * 3 * d, Kd), generator=g) * 0.06).to(torch.bfloat16)
+        b_phys = torch.randn(L * 3 * d, generator=g) * 0.1
+        rows = torch.cat([torch.arange(3 * d * l + d, 3 * d * (l + 1)) for l in range(L)])
+        w, bias = w_phys[rows], b_phys[rows]
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+        K.gemm_row_groups(a.to(DEV), w_phys.to(DEV), out, M, N, Kd, bias=b_phys.to(DEV), group=(2 * d, 3 * d, d, 1))
+    else:
+        w = (torch.randn((N, Kd), generator=g) * 0.06).to(torch.bfloat16)
+        bias = torch.randn(N, generator=g) * 0.1
+        out = K.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV))
+    idx = torch.randint(0, M, (4096,), generator=g)
+    idx[:4] = torch.tensor([0, 1, M - 2, M - 1])
+    ref = a[idx].double() @ w.double().t() + bias.double()
+    got = out[idx.to(DEV)].double().cpu()
+    err = (got - ref).abs().max().item()
+    assert err <= 2 ** -8 * ref.abs().max().item() + 1e-3, err           # one bf16 rounding of the fp32-accumulated value
+    assert torch.isfinite(out).all()
