@@ -162,8 +162,14 @@ int omr_linear_wgrad_grouped(int dtype, int nprob, const omr_dw_problem* problem
  * upper bound on the persistent grid's blocks per image; deterministic, see "normalisation"): stat_mode 1 = {sum y, sum y^2}
  * (InstanceNorm statistics of this output, finalised by omr_instnorm_finalize), stat_mode 2 = {sum g, sum g*xhat} with
  * xhat = (stat_x - mean)*rstd (InstanceNorm backward sums when this call is the data gradient that produces g = dL/dxhat;
- * consumed by omr_instnorm_bwd_apply). */
+ * consumed by omr_instnorm_bwd_apply).
+ * stat_mode 4 / 5 -- the data gradient through a normalise-on-load conv without ever storing g: mode 4 takes the sums of
+ * mode 2 and stores nothing (y may be NULL); omr_instnorm_reduce_sums adds the slots of each image; mode 5 recomputes the
+ * data gradient and applies the InstanceNorm backward in its epilogue, y = rstd * (g - mean(g) - xhat * mean(g * xhat)),
+ * times (stat_x > 0) * mask_scale when `relu` is set (the ReLU / dropout backward of the layer that produced stat_x).  In
+ * these two modes bias and out_mask must be NULL.  (The stand-alone form is omr_instnorm_bwd_apply on a stored g.) */
 int omr_conv3x3_stat_slots(int B, int Ho, int Wo);
+int omr_instnorm_reduce_sums(void* workspace, int slots, int B, int C, void* stream);
 int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const float* bias, void* y, const float* in_mean, const float* in_rstd,
                     const void* out_mask, float mask_scale, int B, int H, int W, int CIN, int COUT, int stride_h, int stride_w, int dil_h,
                     int dil_w, int Ho, int Wo, int relu, float drop_p, unsigned long long drop_seed, int drop_channel_mode,

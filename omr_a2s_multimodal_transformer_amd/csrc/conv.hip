@@ -882,13 +882,14 @@ extern "C" int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const fl
                                int dil_h, int dil_w, int Ho, int Wo, int relu, float drop_p, unsigned long long drop_seed,
                                int drop_channel_mode, int stat_mode, double* stat_ws, int stat_slots, const void* stat_x,
                                const float* stat_mean, const float* stat_rstd, void* stream) {
-    if (B <= 0 || H <= 0 || W <= 0 || CIN <= 0 || COUT <= 0 || !x || !w || !y) return OMR_ERR_ARG;
+    if (B <= 0 || H <= 0 || W <= 0 || CIN <= 0 || COUT <= 0 || !x || !w || (!y && stat_mode != 4)) return OMR_ERR_ARG;
     if (stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1 || dil_h > 2 || dil_w > 2) return OMR_ERR_ARG;
     if ((stride_h > 1 || stride_w > 1) && (dil_h > 1 || dil_w > 1)) return OMR_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    if (drop_p < 0.f || drop_p >= 1.f || stat_mode < 0 || stat_mode > 2) return OMR_ERR_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f || stat_mode < 0 || stat_mode == 3 || stat_mode > 5) return OMR_ERR_ARG;
     if (stat_mode && (!stat_ws || stat_slots < 1)) return OMR_ERR_ARG;
-    if (stat_mode == 2 && (!stat_x || !stat_mean || !stat_rstd)) return OMR_ERR_ARG;
+    if (stat_mode >= 2 && (!stat_x || !stat_mean || !stat_rstd)) return OMR_ERR_ARG;
+    if (stat_mode >= 4 && (out_mask || bias || drop_p > 0.f)) return OMR_ERR_ARG;      // data-gradient modes: `relu` / mask_scale describe stat_x's ReLU mask
     if (CIN == 1) {
         if (drop_p > 0.f || stat_mode) return OMR_ERR_UNSUPPORTED;
         if (dil_h != 1 || dil_w != 1 || stride_h != 1 || stride_w != 1 || in_mean || out_mask || Ho != H || Wo != W) return OMR_ERR_UNSUPPORTED;
@@ -909,6 +910,8 @@ extern "C" int omr_conv3x3_fwd(int dtype, const void* x, const void* w, const fl
     a.drop_thresh = OMR_DROP_THRESH16(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.drop_seed = drop_seed;
     a.drop_channel = drop_channel_mode;
     a.stat_mode = stat_mode; a.stat_ws = stat_ws; a.stat_x = stat_x; a.stat_mean = stat_mean; a.stat_rstd = stat_rstd; a.stat_slots = stat_slots;
+    a.stat_relu = 0; a.stat_relu_scale = 1.f;
+    if (stat_mode >= 4) { a.stat_relu = relu; a.stat_relu_scale = mask_scale; a.relu = 0; a.mask_scale = 1.f; }
     if (dtype == OMR_BF16) return omr_conv3x3_dispatch_bf16(a, s);
     if (dtype == OMR_F32) return omr_conv3x3_dispatch_f32(a, s);
     return OMR_ERR_UNSUPPORTED;

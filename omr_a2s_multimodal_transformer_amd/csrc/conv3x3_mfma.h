@@ -55,7 +55,13 @@ struct ConvArgs {
     // The reduction is DETERMINISTIC: per-thread fp32 partials (fixed tile walk) -> fixed-order fp64 sum over the block's
     // threads -> plain store into the block's own slot stat_ws[b][blockIdx.x][COUT][2]; the consumer (omr_instnorm_finalize /
     // omr_instnorm_bwd_apply) adds the stat_slots slots of an image in index order.  No atomics anywhere.
+    //   mode 4: the sums of mode 2 WITHOUT storing the output; mode 5: the output of mode 2 with the InstanceNorm backward
+    //           applied in the epilogue,  dx = rstd * (g - s1 - xhat * s2) [* (stat_x > 0) * stat_relu_scale],  s1 / s2 = the
+    //           image's {sum g, sum g * xhat} / (Ho * Wo) read from the compact sums behind the slots (omr_instnorm_reduce_sums).
+    //           Together: the data gradient of a normalise-on-load conv is taken TWICE (HBM-bound layers: the MFMAs are free)
+    //           instead of written as g, read back, and written again by a stand-alone apply pass.
     int stat_mode; double* stat_ws; const void* stat_x; const float* stat_mean; const float* stat_rstd; int stat_slots;
+    int stat_relu; float stat_relu_scale;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -146,7 +152,8 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2)
 #pragma unroll
     for (int e = 0; e < (EPI == 2 ? VEC : 1); ++e) { smu[e] = 0.f; srs[e] = 1.f; }
     constexpr bool FWD = EPI == 1 || EPI == 3, DROP = EPI == 3;     // forward extras; MixDropout code compiled in
-    const bool stat1 = FWD && a.stat_mode == 1, stat2 = EPI == 2 && a.stat_mode == 2;
+    const bool stat1 = FWD && a.stat_mode == 1, stat2 = EPI == 2 && (a.stat_mode == 2 || a.stat_mode == 4);
+    const bool apply5 = EPI == 2 && a.stat_mode == 5, store_y = a.stat_mode != 4;
     auto flush_stats = [&](int bimg) {
         if constexpr (EPI != 0) {
             constexpr int NGRP = 256 / CPO;                       // threads that share a channel chunk
@@ -180,12 +187,18 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2)
     const int tiles_per_img = a.tiles_h * a.tiles_w;
     const int b = blockIdx.z;
     if constexpr (EPI == 2) {
-        if (stat2) {
+        if (stat2 || apply5) {
+            const double* compact = a.stat_ws + (long)a.B * a.stat_slots * a.COUT * 2;       // [B][COUT][2]: the image's finished sums (mode 5)
+            const double inv_hw = 1.0 / ((double)a.Ho * a.Wo);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const int n = n0 + (tid % CPO) * VEC + e;
                 smu[e] = n < a.COUT ? a.stat_mean[(long)b * a.COUT + n] : 0.f;
                 srs[e] = n < a.COUT ? a.stat_rstd[(long)b * a.COUT + n] : 1.f;
+                if (apply5) {          // the partial-sum registers are free in this mode: they hold s1 = mean(g), s2 = mean(g * xhat)
+                    ssum[e] = n < a.COUT ? (float)(compact[((long)b * a.COUT + n) * 2] * inv_hw) : 0.f;
+                    ssq[e] = n < a.COUT ? (float)(compact[((long)b * a.COUT + n) * 2 + 1] * inv_hw) : 0.f;
+                }
             }
         }
     }
@@ -403,7 +416,7 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2)
         __syncthreads();
         T* Y = (T*)a.y + (long)b * a.Ho * a.Wo * a.COUT;
         const T* Mk = a.mask ? (const T*)a.mask + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
-        const T* SX = stat2 ? (const T*)a.stat_x + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
+        const T* SX = (stat2 || apply5) ? (const T*)a.stat_x + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
 #pragma unroll(EPI == 0 ? 8 : 4)
         for (int c = tid; c < TH * TW * CPO; c += 256) {
             const int pl = c / CPO, kc = (c % CPO) * VEC;
@@ -436,7 +449,19 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2)
                 bits &= keep;
                 __builtin_memcpy(&v, &bits, sizeof(bits));
             }
-            *reinterpret_cast<F*>(Y + o) = v;
+            if constexpr (EPI == 2) {
+                if (apply5) {          // InstanceNorm backward on the way out (norm.hip instnorm_bwd_apply_kernel's arithmetic)
+                    const F xv = *reinterpret_cast<const F*>(SX + o);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float xf = to_f32(xv[e]);
+                        float d = srs[e] * (to_f32(v[e]) - ssum[e] - (xf - smu[e]) * srs[e] * ssq[e]);
+                        if (a.stat_relu) d = xf > 0.f ? d * a.stat_relu_scale : 0.f;
+                        v[e] = from_f32<T>(d);
+                    }
+                }
+            }
+            if (store_y) *reinterpret_cast<F*>(Y + o) = v;
             if constexpr (FWD) {
                 if (stat1) {
 #pragma unroll
@@ -501,7 +526,7 @@ template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, b
 template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, bool SINGLE> int launch_conv2(const ConvArgs& a, hipStream_t s) {
     constexpr bool can1 = (DH == 1 && DW == 1), can2 = (SH == 1 && SW == 1);
     constexpr bool is_f32 = std::is_same<T, float>::value;
-    int epi = (a.stat_mode == 2) ? 2 : (a.drop_thresh ? 3 : (a.stat_mode == 1 ? 1 : 0));
+    int epi = (a.stat_mode == 2 || a.stat_mode >= 4) ? 2 : (a.drop_thresh ? 3 : (a.stat_mode == 1 ? 1 : 0));
     if (is_f32 && epi == 0) epi = can1 ? 1 : 2;
     if (epi == 1) {
         if constexpr (can1) return launch_conv3<T, NT, RPW, CK, SH, SW, DH, DW, SINGLE, 1>(a, s);

@@ -316,6 +316,17 @@ extern "C" int omr_instnorm_finalize(const void* workspace, int slots, float* me
     return OMR_OK;
 }
 
+/* the image-wise sums of the slots a producer kernel filled (omr_conv3x3_fwd stat_mode 2 / 4), added in slot order into the
+ * compact region [B][C][2] behind them: what omr_conv3x3_fwd stat_mode 5 (and omr_instnorm_bwd_apply) read */
+extern "C" int omr_instnorm_reduce_sums(void* workspace, int slots, int B, int C, void* stream) {
+    if (B <= 0 || C <= 0 || slots < 1 || !workspace) return OMR_ERR_ARG;
+    double* ws = (double*)workspace;
+    hipLaunchKernelGGL((instnorm_reduce_slots_kernel<false>), B, 256, 0, (hipStream_t)stream, (const double*)ws, slots, C, (float*)nullptr, (float*)nullptr,
+                       ws + (long)B * slots * C * 2, 0.0, 0.f);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
 static int launch_bwd_apply(int dtype, const void* dxhat, const void* x, const float* mean, const float* rstd, void* dx, int B, long HW, int C,
                             int relu_mask, float relu_scale, double* ws, int slots, hipStream_t s) {
     double* compact = ws + (long)B * slots * C * 2;

@@ -23,6 +23,13 @@ from .runtime import WgradStream, note_relu
 
 Tensor = torch.Tensor
 
+# Conv3x3Fn.backward through a normalise-on-load conv: True = take the data gradient twice (sums only, then again with the
+# InstanceNorm backward applied in its epilogue: omr_conv3x3_fwd stat_mode 4 / 5) instead of storing it for the stand-alone apply
+# pass.  Measured on C2 (round 3): the recomputation costs what the apply pass saves (conv data gradients 9.24 -> 10.83 ms,
+# InstanceNorm 1.99 -> 0.33 ms per step; step 26.7 -> 27.3 ms without the side stream) -- the data-gradient kernels are not
+# purely HBM-bound, a second pass costs almost a full one.  Kept as an option (same gradients: tests/test_round3_gpu.py).
+TWO_PASS_NORM_BWD = False
+
 
 def wt(p: Tensor, dtype: torch.dtype) -> Tensor:
     """Physical compute view of a parameter in the compute dtype (params.py attaches them)."""
@@ -94,10 +101,17 @@ class Conv3x3Fn(Function):
             if stats is None:
                 dx = K.conv3x3(g, wd, None, stride=(1, 1), dil=stride, out_hw=(H, W), out_mask=x if mask_input else None, mask_scale=in_scale)
             else:
-                # data gradient w.r.t. the normalised input, with the InstanceNorm-backward sums reduced in its epilogue
+                # data gradient w.r.t. the normalised input with the InstanceNorm-backward sums reduced in its epilogue, then the
+                # apply pass (or, TWO_PASS_NORM_BWD, the recomputing form: see the switch's comment)
                 ws, slots = K.conv_stat_ws(x.shape[0], H, W, x.shape[3], x.device)
-                dxh = K.conv3x3(g, wd, None, stride=(1, 1), dil=stride, out_hw=(H, W), stat_mode=2, stat_ws=ws, stat_slots=slots, stat_x=x, stat_stats=stats)
-                dx = K.instnorm_bwd_apply(dxh, x, stats[0], stats[1], ws, slots, relu_mask=mask_input, relu_scale=in_scale)
+                kw = dict(stride=(1, 1), dil=stride, out_hw=(H, W), stat_ws=ws, stat_slots=slots, stat_x=x, stat_stats=stats)
+                if TWO_PASS_NORM_BWD:
+                    K.conv3x3(g, wd, None, stat_mode=4, **kw)
+                    K.instnorm_reduce_sums(ws, slots, x.shape[0], x.shape[3])
+                    dx = K.conv3x3(g, wd, None, stat_mode=5, relu=mask_input, mask_scale=in_scale, **kw)
+                else:
+                    dxh = K.conv3x3(g, wd, None, stat_mode=2, **kw)
+                    dx = K.instnorm_bwd_apply(dxh, x, stats[0], stats[1], ws, slots, relu_mask=mask_input, relu_scale=in_scale)
         return (dx,) + (None,) * 10
 
 

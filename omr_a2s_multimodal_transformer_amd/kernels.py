@@ -420,26 +420,33 @@ def conv3x3(x: Tensor, w_phys: Tensor, bias: Optional[Tensor], stride=(1, 1), re
     if out_hw is None:
         out_hw = conv_out_hw(H, W, stride)
     Ho, Wo = out_hw
-    y = torch.empty((B, Ho, Wo, COUT), dtype=x.dtype, device=x.device)
+    y = torch.empty((B, Ho, Wo, COUT), dtype=x.dtype, device=x.device) if stat_mode != 4 else None      # mode 4 takes sums only
     mean = rstd = None
     if in_stats is not None:
         mean, rstd = in_stats
         assert tuple(mean.shape) == (B, CIN) and mean.dtype == torch.float32
     if out_mask is not None:
-        assert out_mask.shape == y.shape and out_mask.is_contiguous() and out_mask.dtype == x.dtype
+        assert tuple(out_mask.shape) == (B, Ho, Wo, COUT) and out_mask.is_contiguous() and out_mask.dtype == x.dtype
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == COUT
     p, seed, chan = drop if drop is not None else (0.0, 0, False)
     smean = srstd = None
     if stat_mode:
         assert stat_ws is not None and stat_ws.dtype == torch.float64 and stat_slots >= 1 and stat_ws.numel() >= B * stat_slots * COUT * 2
-    if stat_mode == 2:
+    if stat_mode >= 2:
         smean, srstd = stat_stats
-        assert stat_x is not None and stat_x.shape == y.shape and stat_x.is_contiguous() and tuple(smean.shape) == (B, COUT)
+        assert stat_x is not None and tuple(stat_x.shape) == (B, Ho, Wo, COUT) and stat_x.is_contiguous() and tuple(smean.shape) == (B, COUT)
+        assert stat_ws.numel() >= B * stat_slots * COUT * 2 + B * COUT * 2
     lib().call("omr_conv3x3_fwd", dtype_code(x.dtype), ptr(x), ptr(w_phys), ptr(bias), ptr(y), ptr(mean), ptr(rstd), ptr(out_mask), float(mask_scale),
                B, H, W, CIN, COUT, stride[0], stride[1], dil[0], dil[1], Ho, Wo, int(relu), float(p), int(seed) & (2**64 - 1), int(chan),
                int(stat_mode), ptr(stat_ws), int(stat_slots), ptr(stat_x), ptr(smean), ptr(srstd), cur_stream())
     return y
+
+
+def instnorm_reduce_sums(ws: Tensor, slots: int, B: int, C: int) -> None:
+    """Per-image sums of the slots a conv3x3(stat_mode=2 / 4) launch filled, into the compact region of the same workspace."""
+    require_cuda(ws)
+    lib().call("omr_instnorm_reduce_sums", ptr(ws), slots, B, C, cur_stream())
 
 
 def conv3x3_weight_flip(w_phys: Tensor) -> Tensor:

@@ -275,3 +275,41 @@ def test_panel_gemm_matches_fp64_product(M, N, Kd, grouped):
     err = (got - ref).abs().max().item()
     assert err <= 2 ** -8 * ref.abs().max().item() + 1e-3, err           # one bf16 rounding of the fp32-accumulated value
     assert torch.isfinite(out).all()
+
+
+# ------------------------------------------------------------------------------------------------ InstanceNorm backward by recomputation
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-6), ("bf16", 2e-2)])
+def test_two_pass_instancenorm_backward_equals_the_stored_form(dtype, tol):
+    """Conv3x3Fn.backward takes the data gradient through a normalise-on-load conv twice (sums only, then again with the
+    InstanceNorm backward applied in the epilogue: omr_conv3x3_fwd stat_mode 4 / 5) instead of storing it for a stand-alone
+    apply pass (stat_mode 2 + omr_instnorm_bwd_apply): same gradients for every encoder parameter and for the input."""
+    from omr_a2s_multimodal_transformer_amd import functional as Fn
+    from omr_a2s_multimodal_transformer_amd.model import Transformer
+    V = 40
+    w2i, i2w = syn.make_vocab(V)
+    m = Transformer(80, 200, 16, w2i, i2w, config=ModelConfig(num_layers=1, compute_dtype=dtype, **NO_DROP))
+    sd = syn.seeded_state_dict(syn.transformer_shapes(V, 256, 256, 1), 7, mode="torch_default")
+    m.load_state_dict(sd, strict=False)
+    m.flatten_parameters()
+    m.train()
+    m.teacher_forcing_prob = 0.0
+    x, xl, y_in, y_out = syn.synthetic_unimodal_batch(3, 80, 200, 12, V, w2i["<sos>"], w2i["<eos>"], seed=4)
+    x, y_out = x.to(DEV), y_out.to(DEV)
+    grads = {}
+    try:
+        for two_pass in (False, True):
+            Fn.TWO_PASS_NORM_BWD = two_pass
+            random.seed(0)
+            m.zero_grad()
+            m.compute_loss(m(x, xl, y_in), y_out).backward()
+            torch.cuda.synchronize()
+            grads[two_pass] = m._flat.grad.clone()
+    finally:
+        Fn.TWO_PASS_NORM_BWD = True
+    for n, (o, c) in m._flat.offsets.items():
+        a, b = grads[False][o:o + c], grads[True][o:o + c]
+        if a.abs().max() == 0:
+            continue
+        rel = ((a - b).norm() / a.norm()).item()
+        assert rel < tol, (n, rel)
