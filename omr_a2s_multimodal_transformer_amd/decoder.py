@@ -130,9 +130,16 @@ class TransformerDecoderLayer(nn.Module):
         self.norm1, self.norm2, self.norm3 = LayerNorm(d_model), LayerNorm(d_model), LayerNorm(d_model)
         self.dropout_p = dropout
 
+    fused_node = True       # one autograd node per layer (functional.DecoderLayerFn) instead of one per operation: same kernels, same bits
+
     def forward(self, x, memory, window: int, self_key_bias, mem_key_bias, kv=None):
         """kv: this layer's cross-attention K|V of `memory` when the decoder projected all layers at once."""
         tr, p = self.training, self.dropout_p
+        if self.fused_node and kv is not None and x.is_contiguous():
+            pp = p if tr else 0.0
+            # the seeds of the layer's six dropout sites, drawn in the order the per-operation path draws them
+            seeds = tuple(next_seed(kind, pp) for kind in ("attn", "rows", "attn", "rows", "rows", "rows")) if pp > 0.0 else (0,) * 6
+            return Fn.DecoderLayerFn.apply(x, kv, self, window, self_key_bias, mem_key_bias, pp, seeds)
         drop = (lambda: (p, next_seed("rows", p))) if (tr and p > 0.0) else (lambda: None)      # dropout1/2/3 ride inside the add+LayerNorm kernels
         sa = self.self_attn.self_attention(x, True, window, self_key_bias, tr)
         x = Fn.AddLayerNormFn.apply(sa, x, self.norm1.weight, self.norm1.bias, drop())

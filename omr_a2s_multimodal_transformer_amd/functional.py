@@ -336,6 +336,107 @@ class AttentionFn(Function):
         return dqkv, dkv, None, None, None, None, None, None, None, None
 
 
+class DecoderLayerFn(Function):
+    """One post-norm decoder layer (torch nn/modules/transformer.py:1129-1199 as configured at decoder.py:86-95) as ONE autograd
+    node: the eleven kernels of the forward pass and the ~20 of the backward pass are the same launches, in the same order and
+    with the same operands, as the per-operation nodes (LinearFn, AttentionFn, AddLayerNormFn) issue -- results are identical to
+    the bit -- but the host pays for one node instead of eleven: per-node autograd bookkeeping is most of the host time of the
+    small configurations (C1 / C3 / C4 are host-issue bound).  `seeds` = (attn1, drop1, attn2, drop2, ffn, drop3) drawn by the
+    caller in the per-operation order (runtime.next_seed), p = the layer's dropout probability (0 in eval mode)."""
+
+    @staticmethod
+    def forward(ctx, x, kv, layer, window, self_bias, mem_bias, p, seeds):
+        sa, ca = layer.self_attn, layer.multihead_attn
+        dt = x.dtype
+        B, T, d = x.shape
+        S, H, dev = kv.shape[1], sa.num_heads, x.device
+        x2 = x.reshape(-1, d)
+
+        def lin(inp2, weight, bias, rows=None, relu=False, drop=None):
+            w = wt(weight, dt)
+            w = w.view(w.shape[0], -1)
+            b = bias.omr_phys
+            if rows is not None:
+                w, b = w[rows[0]:rows[1]], b[rows[0]:rows[1]]
+            return K.gemm(inp2, w, bias=b, relu=relu, drop=drop)
+
+        def words(Tq, Sk, seed):
+            return WgradStream.prepare(lambda: K.attn_dropout_words(B, H, Tq, Sk, p, seed, dev), dev) if p > 0.0 else None
+
+        drop = (lambda i: (p, seeds[i])) if p > 0.0 else (lambda i: None)
+        # self-attention block
+        qkv = lin(x2, sa.in_proj_weight, sa.in_proj_bias).view(B, T, 3 * d)
+        w1 = words(T, T, seeds[0])
+        o1, lse1 = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, causal=True, window=window, key_bias=self_bias,
+                              dropout_p=p, seed=seeds[0], drop_words=w1)
+        a1 = lin(o1.view(-1, d), sa.out_proj.weight, sa.out_proj.bias).view(B, T, d)
+        x1, mean1, rstd1 = K.add_layernorm_fwd(a1, x, layer.norm1.weight.omr_phys, layer.norm1.bias.omr_phys, drop_p=p, drop_seed=seeds[1])
+        # cross-attention block
+        q2 = lin(x1.view(-1, d), ca.in_proj_weight, ca.in_proj_bias, rows=(0, d)).view(B, T, d)
+        w2 = words(T, S, seeds[2])
+        o2, lse2 = K.attn_fwd(q2, kv[..., :d], kv[..., d:], H, causal=False, window=-1, key_bias=mem_bias, dropout_p=p, seed=seeds[2], drop_words=w2)
+        a2 = lin(o2.view(-1, d), ca.out_proj.weight, ca.out_proj.bias).view(B, T, d)
+        x2n, mean2, rstd2 = K.add_layernorm_fwd(a2, x1, layer.norm2.weight.omr_phys, layer.norm2.bias.omr_phys, drop_p=p, drop_seed=seeds[3])
+        # feed-forward block (ReLU + dropout in the first GEMM's epilogue)
+        h = lin(x2n.view(-1, d), layer.linear1.weight, layer.linear1.bias, relu=True, drop=drop(4))
+        note_relu(h.view(B, T, -1))
+        f = lin(h, layer.linear2.weight, layer.linear2.bias).view(B, T, d)
+        y, mean3, rstd3 = K.add_layernorm_fwd(f, x2n, layer.norm3.weight.omr_phys, layer.norm3.bias.omr_phys, drop_p=p, drop_seed=seeds[5])
+        ctx.layer, ctx.cfg = layer, (window, p, seeds, H, d)
+        ctx.kv_sink = getattr(kv, "omr_grad_sink", None)
+        ctx.words = (w1, w2)
+        ctx.save_for_backward(x, kv, self_bias, mem_bias, qkv, o1, lse1, a1, x1, mean1, rstd1, q2, o2, lse2, a2, x2n, mean2, rstd2, h, f, mean3, rstd3)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        layer = ctx.layer
+        window, p, seeds, H, d = ctx.cfg
+        x, kv, self_bias, mem_bias, qkv, o1, lse1, a1, x1, mean1, rstd1, q2, o2, lse2, a2, x2n, mean2, rstd2, h, f, mean3, rstd3 = ctx.saved_tensors
+        sa, ca = layer.self_attn, layer.multihead_attn
+        dt = x.dtype
+        B, T, _ = x.shape
+
+        def ln_bwd(g, branch, res, norm, mean, rstd, seed):
+            r = K.add_layernorm_bwd(g.contiguous(), branch, res, norm.weight.omr_phys, mean, rstd, norm.weight.omr_grad, norm.bias.omr_grad,
+                                    drop_p=p, drop_seed=seed)
+            if p > 0.0:
+                ds, dbranch = r                        # K.add_layernorm_bwd: (gradient of the residual input, gradient of the dropped branch)
+                return dbranch, ds
+            return r, r                                # (gradient of the sub-layer output, gradient of the residual input)
+
+        def lin_bwd(g2, inp2, weight, bias, rows=None):
+            w = wt(weight, dt)
+            w = w.view(w.shape[0], -1)
+            gw, gb = weight.omr_grad.view(w.shape), bias.omr_grad
+            if rows is not None:
+                w, gw, gb = w[rows[0]:rows[1]], gw[rows[0]:rows[1]], gb[rows[0]:rows[1]]
+            WgradStream.defer_linear(g2, inp2, gw, gb)
+            return K.gemm(g2, w, trans_b=True)
+
+        # feed-forward block
+        df, dres = ln_bwd(gy, f, x2n, layer.norm3, mean3, rstd3, seeds[5])
+        dh = lin_bwd(df.view(-1, d), h, layer.linear2.weight, layer.linear2.bias)
+        g1 = K.relu_bwd(dh, h, 1.0 / (1.0 - p) if p > 0.0 else 1.0)
+        dx2 = dres + lin_bwd(g1, x2n.view(-1, d), layer.linear1.weight, layer.linear1.bias).view(B, T, d)
+        # cross-attention block
+        da2, dres = ln_bwd(dx2, a2, x1, layer.norm2, mean2, rstd2, seeds[3])
+        do2 = lin_bwd(da2.view(-1, d), o2.view(-1, d), ca.out_proj.weight, ca.out_proj.bias).view(B, T, d)
+        dq2 = torch.empty_like(q2)
+        dkv = torch.empty_like(kv) if ctx.kv_sink is None else ctx.kv_sink[0].slot(kv, ctx.kv_sink[1])
+        K.attn_bwd(q2, kv[..., :d], kv[..., d:], o2, do2, lse2, dq2, dkv[..., :d], dkv[..., d:], H, causal=False, window=-1, key_bias=mem_bias,
+                   dropout_p=p, seed=seeds[2], drop_words=ctx.words[1])
+        dx1 = dres + lin_bwd(dq2.view(-1, d), x1.view(-1, d), ca.in_proj_weight, ca.in_proj_bias, rows=(0, d)).view(B, T, d)
+        # self-attention block
+        da1, dres = ln_bwd(dx1, a1, x, layer.norm1, mean1, rstd1, seeds[1])
+        do1 = lin_bwd(da1.view(-1, d), o1.view(-1, d), sa.out_proj.weight, sa.out_proj.bias).view(B, T, d)
+        dqkv = torch.empty_like(qkv)
+        K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o1, do1, lse1, dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:], H,
+                   causal=True, window=window, key_bias=self_bias, dropout_p=p, seed=seeds[0], drop_words=ctx.words[0])
+        dx = dres + lin_bwd(dqkv.view(-1, 3 * d), x.reshape(-1, d), sa.in_proj_weight, sa.in_proj_bias).view(B, T, d)
+        return dx, dkv, None, None, None, None, None, None
+
+
 class KVGradSink:
     """Shared landing buffer for the K|V gradients of all decoder layers: each layer's attention backward writes its
     [B,S,2d] gradient straight into its column block of one [B,S,L*2d] tensor, so FusedCrossKVFn.backward can run ONE

@@ -313,3 +313,48 @@ def test_two_pass_instancenorm_backward_equals_the_stored_form(dtype, tol):
             continue
         rel = ((a - b).norm() / a.norm()).item()
         assert rel < tol, (n, rel)
+
+
+# ------------------------------------------------------------------------------------------------ one autograd node per decoder layer
+
+@pytest.mark.parametrize("dtype,drop", [("fp32", 0.0), ("fp32", 0.1), ("bf16", 0.1)])
+def test_fused_decoder_layer_node_equals_the_per_operation_nodes(dtype, drop):
+    """functional.DecoderLayerFn issues the launches of a decoder layer from one autograd node: logits and loss are identical
+    to the bit with the per-operation path (LinearFn / AttentionFn / AddLayerNormFn), the gradients up to the fp32 atomics of
+    the weight-gradient reductions; the dropout-site trace (kinds, order, seeds) is the same."""
+    from omr_a2s_multimodal_transformer_amd.decoder import TransformerDecoderLayer
+    from omr_a2s_multimodal_transformer_amd.model import Transformer
+    from omr_a2s_multimodal_transformer_amd.runtime import seed_dropout, trace_dropout
+    V, L = 60, 3
+    w2i, i2w = syn.make_vocab(V)
+    m = Transformer(64, 160, 40, w2i, i2w, attn_window=9, config=ModelConfig(num_layers=L, compute_dtype=dtype, dropout=drop, encoder_dropout=0.0))
+    sd = syn.seeded_state_dict(syn.transformer_shapes(V, 256, 256, L), 13, mode="torch_default")
+    m.load_state_dict(sd, strict=False)
+    m.flatten_parameters()
+    m.train()
+    m.teacher_forcing_prob = 0.0
+    x, xl, y_in, y_out = syn.synthetic_unimodal_batch(3, 64, 160, 33, V, w2i["<sos>"], w2i["<eos>"], seed=8)
+    x, y_out = x.to(DEV), y_out.to(DEV)
+    res = {}
+    try:
+        for fused in (False, True):
+            TransformerDecoderLayer.fused_node = fused
+            seed_dropout(77)
+            random.seed(0)
+            m.zero_grad()
+            with trace_dropout() as tr:
+                logits = m(x, xl, y_in)
+                loss = m.compute_loss(logits, y_out)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[fused] = (logits.detach().clone(), loss.detach().clone(), m._flat.grad.clone(), list(tr))
+    finally:
+        TransformerDecoderLayer.fused_node = True
+    assert res[False][3] == res[True][3] and (drop == 0.0 or len(res[True][3]) >= 6 * L)
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+    for n, (o, c) in m._flat.offsets.items():
+        a, b = res[False][2][o:o + c], res[True][2][o:o + c]
+        if a.abs().max() == 0:
+            continue
+        rel = ((a - b).norm() / a.norm()).item()
+        assert rel < (1e-5 if dtype == "fp32" else 2e-3), (n, rel)
