@@ -213,7 +213,13 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
     for (int st = 0; st < NSTAGE - 1; ++st) issue(tile + st * (int)gridDim.x, st);
     int cur = 0, stat_b = -1, stat_slot = 0;
     const float* sstat = sstat_base;
-    float rs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, nb8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // NORM, rows <= 64 B: this thread's channel statistics
+    float rs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, nb8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // NORM: this thread's channel statistics
+    // 128-byte rows (CBC = 64): the placement swaps the 64-byte halves of every other pixel pair, so a thread meets TWO channel
+    // chunks (c and c ^ 4): the second set.  (Reading the statistics from LDS per element instead cost 16 scalar LDS reads per
+    // 16-byte chunk: 80 per thread and tile on the strided 64-channel layers.)
+    float rs8b[CBC == 64 ? 8 : 1], nb8b[CBC == 64 ? 8 : 1];
+#pragma unroll
+    for (int e = 0; e < (CBC == 64 ? 8 : 1); ++e) { rs8b[e] = 0.f; nb8b[e] = 0.f; }
     for (; tile < ntiles; tile += gridDim.x) {
         // tile `cur` has landed in every wave's share; the slot consumed in the previous iteration is free again
         if (!DBG(16)) dma_wait_barrier<(NSTAGE - 2) * DMA_PER_TILE>();
@@ -230,10 +236,13 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
                 stat_b = b;
                 stat_slot = (stat_slot + 1) & 7;
                 sstat = sstat_base + stat_slot * 128;
-                if constexpr (CBC <= 32) {
-                    const int cf = (tid % (CBC / 8)) * 8;
+                const int cf = (tid % (CBC / 8)) * 8;          // NTHR is a multiple of the chunks per row: fixed for the thread
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { rs8[e] = sstat[CBC + cf + e]; nb8[e] = -sstat[cf + e] * rs8[e]; }
+                for (int e = 0; e < 8; ++e) { rs8[e] = sstat[CBC + cf + e]; nb8[e] = -sstat[cf + e] * rs8[e]; }
+                if constexpr (CBC == 64) {
+                    const int cg = cf ^ 32;                    // chunk c ^ 4
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { rs8b[e] = sstat[CBC + cg + e]; nb8b[e] = -sstat[cg + e] * rs8b[e]; }
                 }
             }
             issue(tile + (NSTAGE - 1) * (int)gridDim.x, nslot);
@@ -255,8 +264,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(WgradArgs a) {
                 } else {
                     int pix, c;
                     PX::source(r * NTHR + tid, pix, c);
+                    const bool other = c != (tid % (CBC / 8));      // the slot holds chunk (L % 8) ^ 4 of its pixel
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (bf16)(((float)v[e] - sstat[c * 8 + e]) * sstat[CBC + c * 8 + e]);
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16)fmaf((float)v[e], other ? rs8b[e] : rs8[e], other ? nb8b[e] : nb8[e]);
                 }
                 *reinterpret_cast<bf16x8*>(px) = v;
             }
@@ -369,6 +379,7 @@ template <int CBN, int CBC, int TH, int SH, int SW, int NW, int NSTAGE, bool NOR
 template <int SH, int SW, bool NORM> int pick(const WgradArgs& a, hipStream_t s) {
     const int cn = a.COUT > 32 ? 64 : a.COUT > 16 ? 32 : 16, cc = a.CIN > 32 ? 64 : a.CIN > 16 ? 32 : 16;
     if constexpr (SH == 1 && SW == 1) {
+        // (4-row tiles with a 3-deep ring -- two tiles in flight -- were measured in round 3: 439 -> 457 us at 64 -> 64, 402 -> 435 us at 128 -> 128)
         if (cn == 64 && cc == 64) return launch<64, 64, 8, 1, 1, 8, 2, NORM>(a, s);
         if (cn == 64 && cc == 32) return launch<64, 32, 8, 1, 1, 8, 2, NORM>(a, s);
         if (cn == 32 && cc == 64) return launch<32, 64, 8, 1, 1, 8, 2, NORM>(a, s);
