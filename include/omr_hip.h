@@ -184,6 +184,16 @@ int omr_conv3x3_weight_flip_grouped(int dtype, int n, const omr_flip_desc* descs
 /* dw[COUT][3][3][CIN] (fp32) += dy^T * im2col(x);  db[COUT] (nullable, fp32) += column sums of dy (bias gradient) */
 int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, float* db, const float* in_mean, const float* in_rstd, int B, int H, int W,
                       int CIN, int COUT, int stride_h, int stride_w, int Ho, int Wo, void* stream);
+/* The whole backward of a stride-1 3x3 conv with CIN, COUT in {16, 32} (bf16; (COUT, CIN) = (32,32), (32,16), (16,16)) in one pass
+ * over its operands (aten::convolution_backward of nn.Conv2d, encoder.py:132-150): dx = conv^T(g) [* (x > 0) * mask_scale],
+ * dw[COUT][3][3][CIN] += g^T im2col(x), db[COUT] (nullable) += column sums of g.  w_flipped = omr_conv3x3_weight_flip(w).
+ * norm_y != NULL: g is dL/d(InstanceNorm output) of the layer above and norm_y that layer's input (= this conv's stored output);
+ * the InstanceNorm backward (omr_instnorm_bwd_apply's arithmetic, sums from norm_workspace after omr_instnorm_reduce_sums)
+ * and the ReLU / dropout mask of norm_y are applied while the tile is loaded, so the gradient w.r.t. this conv's output never
+ * exists in memory.  OMR_ERR_UNSUPPORTED for other shapes (callers then use omr_conv3x3_fwd + omr_conv3x3_wgrad). */
+int omr_conv3x3_bwd_fused(const void* g, const void* x, const void* w_flipped, void* dx, float* dw, float* db, int B, int H, int W, int CIN,
+                          int COUT, int mask_input, float mask_scale, const void* norm_y, const float* norm_mean, const float* norm_rstd,
+                          const void* norm_workspace, int norm_slots, int relu_mask, float relu_scale, void* stream);
 /* depthwise 3x3, stride 1, pad 1 (DepthSepConv2D.depth_conv, encoder.py:56-64); flip=1 mirrors the taps (data gradient) */
 int omr_dwconv3x3(int dtype, const void* x, const void* w, const float* bias, void* y, const float* in_mean, const float* in_rstd,
                   const void* out_mask, float mask_scale, int B, int H, int W, int C, int flip, void* stream);

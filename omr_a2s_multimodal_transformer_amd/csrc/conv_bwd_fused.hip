@@ -1,0 +1,468 @@
+// Backward of a stride-1 3x3 convolution with <= 32 channels on either side, bf16, in ONE pass over its operands
+// (aten::convolution_backward of nn.Conv2d, reference encoder.py:132-150, for the full-resolution layers of the first two
+// ConvBlocks -- where the bytes of the encoder are):
+//     dX[q][ci]       = sum_tap sum_co G[q + tap - 1][co] * Wflip[ci][tap][co]      * (X[q][ci] > 0) * mask_scale
+//     dW[co][8-tap][ci] += sum_q   G[q + tap - 1][co] * X[q][ci]
+//     db[co]          += sum_q    G[q][co]
+// Why one kernel: these layers are HBM-bound (16 / 32 channels: 37-75 FLOP per byte), the data gradient already reads the G
+// halo tile AND the X tile of the same pixels (its ReLU mask), which are exactly the operands of the weight gradient of the
+// same tile -- summed over the X pixels q the tile owns, with G taken from the halo, every (q, tap) pair of the image is met
+// exactly once.  The separate weight-gradient kernel read both tensors a second time (5.9 GB per C2 step).
+//
+// One 16-wave workgroup per CU, persistent over the 8 x 32 tiles of ONE image (grid z = image):
+//   * operand tiles travel global -> LDS asynchronously (global_load_lds_dwordx4, dma_common.h) into a ring of 2-6 slots: the
+//     next one to five tiles (G halo 10 x 34 pixels + X tile each; 53-97 KB) are in flight behind the current tile's math, no staging
+//     registers; out-of-image pixels are fetched from a line of zeros.  Only waves 8-15 issue DMA and they issue nothing else
+//     that counts in vmcnt, so "tile landed" is an exact s_waitcnt; only waves 0-7 store to global memory.
+//   * LDS tiles are dense pixel-major rows with the 16-byte chunk index XORed by a function of the pixel's COLUMN (the DMA
+//     permutes the source chunk instead of the destination): conflict-free for the data gradient's 16-byte row reads (16
+//     consecutive pixels, one chunk) and for the transposing ds_read_b64_tr_b16 of the weight gradient; because the swizzle
+//     depends on the column only, every address in the MFMA loops is a per-lane base + a compile-time offset;
+//   * data gradient (waves 0-7): wave w owns tile row w: D[ci][pixel], 9 taps x (CO / 16) k-steps, accumulators -> LDS staging
+//     tile -> masked 16-byte row stores;
+//   * weight gradient (waves 8-15): K = the tile's 256 pixels in 16 slabs of 16; wave w owns tap w for all slabs plus a quarter
+//     of the slabs of tap 8 (waves 0-3) or of the bias gradient = centre tap against a fragment of ones (waves 4-7): 20 MFMAs per
+//     wave and tile; its accumulators hold sums nobody else has and leave by one atomic per element per workgroup at the end;
+//   * APPLY: G is not stored anywhere -- it is the InstanceNorm backward of the layer above,
+//     G = (Y > 0) * relu_scale * rstd * (Ghat - mean(Ghat) - yhat * mean(Ghat * yhat)),   yhat = (Y - mean) * rstd,
+//     computed in LDS from the Ghat and Y halo tiles the ring delivers (an in-place pass before the MFMAs): the stand-alone
+//     apply pass (norm.hip), its output and both re-reads of it go.
+#include <atomic>
+#include <type_traits>
+#include "omr_common.h"
+#include "omr_hip.h"
+#include "dma_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) bf16x4 LdsV4;
+constexpr int TW = 32, TH = 8, IH = TH + 2, IW = TW + 2, NHALO = IH * IW, NCORE = TH * TW;
+constexpr int NDG = 512, NWG = 512;           // threads of the data-gradient / weight-gradient halves of the workgroup
+constexpr int NLD = NWG;                      // the weight-gradient waves also issue the DMA
+
+__device__ uint4 g_zero_line;                 // 16 zero bytes: the DMA source of every out-of-image chunk
+
+template <int CB> struct Tile {               // dense pixel-major LDS tile with CB channels; all offsets in bytes
+    static constexpr int CPP = CB / 8, PITCH = CB * 2;
+    __device__ static __forceinline__ int swz(int col) { return CB == 32 ? (col >> 2) & 3 : (col >> 3) & 1; }
+    __device__ static __forceinline__ int chunk(int pix, int col, int c) { return pix * PITCH + ((c ^ swz(col)) << 4); }
+    // address a lane hands to ds_read_b64_tr_b16 for pixel (pix, col), channels 16 cb + 4 p .. + 3.  16-channel tiles have no
+    // channels 16..31: their cb = 1 lanes repeat the cb = 0 address (a broadcast), feeding rows / columns >= 16 of the product
+    // with a copy nobody stores
+    __device__ static __forceinline__ int tr(int pix, int col, int cb, int p) {
+        return pix * PITCH + ((((CB == 32 ? 2 * cb : 0) + (p >> 1)) ^ swz(col)) << 4) + ((p & 1) << 3);
+    }
+};
+
+// DMA descriptor of one operand tile (NPIXT pixels in rows of IWT): LDS chunk slot L holds channel chunk (L % CPP) ^ swz(column) of
+// pixel L / CPP.  Per round a lane keeps the element offset of its source chunk from the tile-origin pixel and its (row, column);
+// every issuing wave executes exactly ROUNDS instructions with all lanes active (lanes past the tile fetch zeros, waves whose 64
+// chunks lie wholly past it write a scratch KB), so the waits can count.
+template <int CB, int IWT, int NPIXT> struct Issuer {
+    static constexpr int CPP = CB / 8, NCH = NPIXT * CPP, WINS = (NCH + 63) / 64, ROUNDS = (WINS * 64 + NLD - 1) / NLD, BYTES = WINS * 1024;
+    int rel[ROUNDS], ij[ROUNDS];
+    __device__ __forceinline__ void init(int Wimg, int wtid) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int L = r * NLD + wtid, pix = L / CPP, il = pix / IWT, jl = pix - il * IWT;
+            const int c = (L % CPP) ^ Tile<CB>::swz(jl);
+            ij[r] = il | (jl << 16);
+            rel[r] = L < NCH ? (il * Wimg + jl) * CB + c * 8 : -1;
+        }
+    }
+    __device__ __forceinline__ void issue(const bf16* origin, int y0, int x0, int Himg, int Wimg, bool interior, unsigned lds_base, unsigned scratch,
+                                          int wtid) const {
+        const bf16* zsrc = reinterpret_cast<const bf16*>(&g_zero_line);
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            bool ok = rel[r] >= 0;
+            if (!interior) {
+                const int ih = y0 + (ij[r] & 0xffff), iw = x0 + (ij[r] >> 16);
+                ok = ok && (unsigned)ih < (unsigned)Himg && (unsigned)iw < (unsigned)Wimg;
+            }
+            const bf16* src = ok ? origin + rel[r] : zsrc;
+            const int L0 = r * NLD + (wtid & ~63);
+            dma16(src, L0 < WINS * 64 ? lds_base + (unsigned)L0 * 16u : scratch);
+        }
+    }
+};
+
+struct FusedArgs {
+    const bf16* g; const bf16* x; const bf16* w; bf16* dx; float* dw; float* db;
+    const bf16* ny; const float* mean; const float* rstd; const double* sums; float inv_hw; float relu_scale;
+    int B, H, W, tiles_w, tiles_h, mask; float mask_scale;
+#ifdef OMR_FUSED_DEBUG
+    int dbg = 0;      // bring-up ablations (OMR_FUSED_DBG=bits): 1 no data-gradient MFMAs, 2 no weight-gradient MFMAs, 4 no stores, 8 no DMA
+#endif
+};
+#ifdef OMR_FUSED_DEBUG
+#include <cstdlib>
+#define DBG(bit) (a.dbg & (bit))
+// phase timing of block (0, 0, 0): wave 0 of each half adds the cycles since its previous mark to g_prof[half][mark]
+__device__ unsigned long long g_prof[2][8];
+#define PROF(k)                                                                                                  \
+    do {                                                                                                         \
+        if (blockIdx.x == 0 && blockIdx.z == 0 && wave == 0) {                                                  \
+            const unsigned long long t__ = __builtin_readcyclecounter();                                         \
+            if (lane == 0) atomicAdd(&g_prof[DG ? 0 : 1][k], t__ - prof_t);                                      \
+            prof_t = t__;                                                                                        \
+        }                                                                                                        \
+    } while (0)
+#else
+#define DBG(bit) false
+#define PROF(k) do {} while (0)
+#endif
+
+// NSLOT = ring depth: NSLOT - 1 tiles are in flight behind the one being consumed (what hides the loaded HBM latency is bytes in
+// flight per CU: 60-100 KB here)
+template <int CO, int CI, bool APPLY, int NSLOT> struct Lds {
+    typedef Issuer<CO, IW, NHALO> IG;
+    typedef Issuer<CI, TW, NCORE> IX;
+    static constexpr int DMA_PER_TILE = IG::ROUNDS * (APPLY ? 2 : 1) + IX::ROUNDS;   // instructions per issuing wave and tile
+    static constexpr int WP = (CO + 8) * 2, OPB = (CI + 8) * 2;                       // weight row / output staging pitch
+    static constexpr int GB = IG::BYTES, XB = IX::BYTES, SLOT = GB * (APPLY ? 2 : 1) + XB;
+    static constexpr int WS = 32 * 9 * WP, OS = NCORE * OPB;
+    static constexpr bool OS_IN_Y = APPLY && OS <= GB;                                // the Y tile is dead once G is formed
+    static constexpr int OFF_WS = NSLOT * SLOT, OFF_OS = OFF_WS + WS, OFF_SCRATCH = OFF_OS + (OS_IN_Y ? 0 : OS), TOTAL = OFF_SCRATCH + 1024;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int off0, int off1, int imm) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(base + off0 + imm));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsV4*)(base + off1 + imm));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// One tile loop, compiled twice: DG = the data-gradient waves (0-7), !DG = the weight-gradient / DMA waves (8-15).  Both meet at the
+// same barriers; each keeps only its own accumulators in registers.
+// Measured alternatives (B = 32, 256 x 2048, 32 -> 32 channels; this form: 1 076 us plain, 1 172-1 212 us with the InstanceNorm apply):
+//   * four separate loader waves (a wave that issues DMA into a busy memory pipe stalls ~1 900 cycles per tile in the issue itself, on
+//     these waves in front of their MFMAs) beside 8 + 4 or 4 + 8 compute waves: 1 118-1 191 us / 1 454-1 616 us -- the MFMA phase is
+//     bound by LDS bandwidth (583 KB of operand reads per tile), concurrent DMA writes stretch it by what the issue stall had cost;
+//   * issuing the DMA behind the MFMAs, beside the store loop: 1 097 / 1 288 us;
+//   * register-staged tiles, two 8-wave workgroups per CU (the conv3x3_mfma.h pipeline): 1 042 us plain, but the apply needs the
+//     second tensor in staging registers too and spills at 128 registers.
+template <int CO, int CI, bool APPLY, int NSLOT, bool DG>
+__device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* smem, const float* cst) {
+    typedef Tile<CO> GT;
+    typedef Tile<CI> XT;
+    typedef Lds<CO, CI, APPLY, NSLOT> L;
+    static_assert(NSLOT >= 2 && (NSLOT - 2) * L::DMA_PER_TILE < 64, "ring depth / vmcnt range");
+    constexpr int XCPP = CI / 8, KC = CO / 16, WP = L::WP, OPB = L::OPB;
+    constexpr bool WG = !DG, LD = !DG;
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.z;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;         // index inside the half; wave-uniform and the compiler knows it
+    const int wtid = tid & 511;
+    const int frow = lane & 31, h = lane >> 5;
+    const unsigned char* Ws = smem + L::OFF_WS;
+    const unsigned lds0 = lds_address(smem);
+
+    const bf16* G = a.g + (long)b * a.H * a.W * CO;
+    const bf16* NY = APPLY ? a.ny + (long)b * a.H * a.W * CO : nullptr;
+    const bf16* X = a.x + (long)b * a.H * a.W * CI;
+    bf16* DX = a.dx + (long)b * a.H * a.W * CI;
+
+    // ---- loaders: DMA descriptors (the Y halo shares the G halo's)
+    typename L::IG ig;
+    typename L::IX ix;
+    if constexpr (LD) { ig.init(a.W, wtid); ix.init(a.W, wtid); }
+    const int tiles_per_img = a.tiles_h * a.tiles_w;
+    const int step_h = (int)gridDim.x / a.tiles_w, step_w = (int)gridDim.x - step_h * a.tiles_w;      // tile (th, tw) -> the block's next tile
+    auto advance = [&](int& th, int& tw) {
+        th += step_h; tw += step_w;
+        if (tw >= a.tiles_w) { tw -= a.tiles_w; ++th; }
+    };
+    auto issue = [&](int th, int tw, int slot) {       // th >= tiles_h: a dummy (zeros) that keeps the in-flight count exact
+        if (DBG(8)) return;
+        const bool live = th < a.tiles_h;
+        const int oh0 = live ? th * TH : -(1 << 20), ow0 = tw * TW;
+        const bool in_g = live && oh0 >= 1 && oh0 + TH + 1 <= a.H && ow0 >= 1 && ow0 + TW + 1 <= a.W;
+        const bool in_x = live && oh0 + TH <= a.H && ow0 + TW <= a.W;
+        const unsigned base = lds0 + (unsigned)(slot * L::SLOT), scratch = lds0 + (unsigned)L::OFF_SCRATCH;
+        const long og = ((long)(oh0 - 1) * a.W + (ow0 - 1)) * CO, ox = ((long)oh0 * a.W + ow0) * CI;
+        ig.issue(G + og, oh0 - 1, ow0 - 1, a.H, a.W, in_g, base, scratch, wtid);
+        if constexpr (APPLY) ig.issue(NY + og, oh0 - 1, ow0 - 1, a.H, a.W, in_g, base + (unsigned)L::GB, scratch, wtid);
+        ix.issue(X + ox, oh0, ow0, a.H, a.W, in_x, base + (unsigned)(L::GB * (APPLY ? 2 : 1)), scratch, wtid);
+    };
+
+    // ---- APPLY: this thread's channel chunk of the in-LDS pass is fixed (1024 % CPP == 0): its constants live in registers
+    constexpr int GCPP = CO / 8, NGCH = NHALO * GCPP, RT = (NGCH + 1023) / 1024;
+    float cA[APPLY ? 8 : 1], cB[APPLY ? 8 : 1], cC[APPLY ? 8 : 1];
+    if constexpr (APPLY) {
+        const int k8 = (tid % GCPP) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { cA[e] = cst[k8 + e]; cB[e] = cst[32 + k8 + e]; cC[e] = cst[64 + k8 + e]; }
+    }
+
+    // ---- per-lane LDS offsets of the MFMA operands (everything the loops add is a compile-time constant)
+    int doff[3];                                             // DG: G fragment of tap column kw: pixel (wave + .., frow + kw), chunk h
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) doff[kw] = GT::chunk(wave * IW + frow + kw, frow + kw, h);
+    const int woff = frow * 9 * WP + h * 16;                 // DG: weight fragment, row ci = frow, k half h
+    const int q = (lane & 15) >> 2, p = lane & 3, cb = (lane >> 4) & 1;
+    // WG: wave w owns tap w for all 16 pixel slabs; its second accumulator takes a quarter of the slabs of tap 8 (waves 0-3) or of the
+    // bias sums = centre tap against ones (waves 4-7): 20 MFMAs per wave and tile (the data-gradient waves: 18).  (Two taps x half the
+    // slabs per wave -- one X fragment for both, 448 transposing reads per tile instead of 576 -- needs a third accumulator: spills.)
+    const bool third_bias = wave >= 4;
+    const bool third = !third_bias || a.db != nullptr;
+    const int third_q = wave & 3;
+    int xo[2], go[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int col = 8 * h + q + 4 * u;
+        xo[u] = XT::tr(col, col, cb, p);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int tap = j == 0 ? wave : (third_bias ? 4 : 8), dr = tap / 3, dc = tap - 3 * dr;
+            go[j][u] = GT::tr(dr * IW + dc + col, dc + col, cb, p);
+        }
+    }
+    f32x16 wacc[WG ? 2 : 1];
+    if constexpr (WG) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wacc[j][r] = 0.f;
+    }
+    const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+
+    const float oscale = a.mask ? a.mask_scale : 1.f;
+#ifdef OMR_FUSED_DEBUG
+    unsigned long long prof_t = __builtin_readcyclecounter();
+#endif
+    int th = (int)blockIdx.x / a.tiles_w, tw = (int)blockIdx.x - th * a.tiles_w;       // this block's first tile
+    int ith = th, itw = tw;                                                          // loaders: the next tile to request
+    if constexpr (LD) {
+#pragma unroll
+        for (int st = 0; st < NSLOT - 1; ++st) { issue(ith, itw, st); advance(ith, itw); }
+    }
+    int cur = 0;
+
+    for (; th < a.tiles_h; advance(th, tw), cur = cur + 1 == NSLOT ? 0 : cur + 1) {
+        const int oh0 = th * TH, ow0 = tw * TW;
+        unsigned char* Gs = smem + cur * L::SLOT;
+        unsigned char* Ys = Gs + L::GB;
+        unsigned char* Xt = Gs + L::GB * (APPLY ? 2 : 1);
+        unsigned char* Os = L::OS_IN_Y ? Ys : smem + L::OFF_OS;
+        // this tile has landed (the DMA waves' only outstanding vector-memory operations are tile pieces, NSLOT - 2 younger tiles may
+        // still be in flight); everybody is done with the slot consumed last (the previous tile's store loop)
+        PROF(0);
+        if constexpr (LD) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSLOT - 2) * L::DMA_PER_TILE) : "memory");
+        PROF(1);
+        __syncthreads();
+        PROF(2);
+        // (issuing after the MFMAs instead, beside the other half's store loop, was measured: 1076 -> 1097 us, 1212 -> 1288 us with two slots)
+        if constexpr (LD) { issue(ith, itw, cur == 0 ? NSLOT - 1 : cur - 1); advance(ith, itw); }
+        PROF(3);
+        if constexpr (APPLY) {
+            // G = cA * Ghat + cB * Y + cC where Y > 0, else 0 (out-of-image pixels arrive as Y = 0), in place over Ghat
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const int c = tid + 1024 * r, pix = c / GCPP;
+                if (c >= NGCH) continue;
+                const int off = GT::chunk(pix, pix % IW, c % GCPP);
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(Gs + off);
+                const bf16x8 y = *reinterpret_cast<const bf16x8*>(Ys + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float yf = (float)y[e];
+                    const float d = fmaf(cA[e], (float)v[e], fmaf(cB[e], yf, cC[e]));
+                    v[e] = (bf16)(yf > 0.f ? d : 0.f);
+                }
+                *reinterpret_cast<bf16x8*>(Gs + off) = v;
+            }
+            __syncthreads();
+        }
+
+        if constexpr (DG) {
+            // ---- data gradient: D[ci][pixel] for tile row `wave`
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < (DBG(1) ? 0 : 9); ++tap) {
+                const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Ws + woff + tap * WP + kc * 32);
+                    const bf16x8 gf = *reinterpret_cast<const bf16x8*>(Gs + (doff[kw] ^ (kc << 5)) + kh * IW * GT::PITCH);
+                    mma32(acc, wf, gf);
+                }
+            }
+            // accumulators -> staging tile (its own LDS, or the dead Y tile)
+            unsigned char* orow = Os + (wave * TW + frow) * OPB + 8 * h;
+#pragma unroll
+            for (int g4 = 0; g4 < XCPP; ++g4) {
+                typedef __attribute__((ext_vector_type(4))) bf16 B4;
+                B4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[4 * g4 + e] * oscale);
+                *reinterpret_cast<B4*>(orow + 16 * g4) = o;
+            }
+        }
+        if constexpr (WG) {
+            // ---- weight gradient: D[co][ci] += G(tap)^T X over the 16 pixel slabs of the tile, four straight-line quarters (the second
+            //      accumulator works in one of them: the wave-uniform test sits outside the unrolled MFMA code)
+            auto slabs = [&](auto quarter_c, auto with_third) {
+                constexpr int QUARTER = decltype(quarter_c)::value;
+                constexpr bool T3 = decltype(with_third)::value;
+#pragma unroll
+                for (int s4 = 0; s4 < (DBG(2) ? 0 : 4); ++s4) {
+                    const int s = QUARTER * 4 + s4;
+                    const int ximm = ((s >> 1) * TW + (s & 1) * 16) * XT::PITCH, gimm = ((s >> 1) * IW + (s & 1) * 16) * GT::PITCH;
+                    const bf16x8 xf = tr_frag(Xt, xo[0], xo[1], ximm);
+                    mma32(wacc[0], tr_frag(Gs, go[0][0], go[0][1], gimm), xf);
+                    if constexpr (T3) mma32(wacc[1], tr_frag(Gs, go[1][0], go[1][1], gimm), third_bias ? ones : xf);
+                }
+            };
+            auto quarter = [&](auto qc) {
+                if (third && third_q == decltype(qc)::value) slabs(qc, std::true_type{});
+                else slabs(qc, std::false_type{});
+            };
+            quarter(std::integral_constant<int, 0>{});
+            quarter(std::integral_constant<int, 1>{});
+            quarter(std::integral_constant<int, 2>{});
+            quarter(std::integral_constant<int, 3>{});
+        }
+        PROF(4);
+        __syncthreads();                          // the staging tile is complete
+        PROF(5);
+        if constexpr (DG) {
+            // ---- masked 16-byte row stores by the data-gradient waves (the only global stores of the kernel: the DMA waves' vmcnt
+            //      must count tile pieces only)
+#pragma unroll
+            for (int j = 0; j < NCORE * XCPP / NDG; ++j) {
+                const int c = wtid + NDG * j, pl = c / XCPP, kc = c - pl * XCPP;
+                const int oh = oh0 + (pl >> 5), ow = ow0 + (pl & 31);
+                if (oh >= a.H || ow >= a.W || DBG(4)) continue;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + pl * OPB + kc * 16);
+                if (a.mask) {
+                    typedef __attribute__((ext_vector_type(8))) short S8;
+                    const S8 m = *reinterpret_cast<const S8*>(Xt + XT::chunk(pl, pl & 31, kc));
+                    const S8 keep = m > (short)0;
+                    S8 bits;
+                    __builtin_memcpy(&bits, &v, sizeof(bits));
+                    bits &= keep;
+                    __builtin_memcpy(&v, &bits, sizeof(bits));
+                }
+                *reinterpret_cast<bf16x8*>(DX + ((long)oh * a.W + ow) * CI + kc * 8) = v;
+            }
+        }
+        PROF(6);
+    }
+
+    if constexpr (LD) dma_drain();        // the trailing dummy DMA must not outlive the workgroup's LDS
+    if constexpr (WG) {
+        // ---- the workgroup's weight-gradient sums: one atomic per element (tap 8 and the bias arrive in four quarters)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j == 1 && third_bias) break;
+            const int tap = j == 0 ? wave : 8, tw8 = 8 - tap;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = acc_row(r, lane), ci = lane & 31;
+                if (co < CO && ci < CI) atomicAdd(&a.dw[((long)co * 9 + tw8) * CI + ci], wacc[j][r]);
+            }
+        }
+        if (third_bias && a.db != nullptr && (lane & 31) == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = acc_row(r, lane);
+                if (co < CO) atomicAdd(&a.db[co], wacc[1][r]);
+            }
+        }
+    }
+}
+
+template <int CO, int CI, bool APPLY, int NSLOT>
+__global__ __launch_bounds__(1024) void conv_bwd_fused_kernel(FusedArgs a) {
+    typedef Lds<CO, CI, APPLY, NSLOT> L;
+    constexpr int GCPP = CO / 8, WP = L::WP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ __attribute__((aligned(16))) float cst[3 * 32];    // APPLY: G = cA * Ghat + cB * Y + cC per channel
+    const int tid = threadIdx.x, b = blockIdx.z;
+    unsigned char* Ws = smem + L::OFF_WS;                          // flipped weights [32 rows ci][9][CO], rows >= CI zero
+    for (int c = tid; c < 32 * 9 * GCPP; c += 1024) {
+        const int row = c / GCPP, kc = c - row * GCPP;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < CI * 9) v = *reinterpret_cast<const bf16x8*>(a.w + (long)row * CO + kc * 8);
+        *reinterpret_cast<bf16x8*>(Ws + row * WP + kc * 16) = v;
+    }
+    if constexpr (APPLY) {
+        if (tid < 32) {
+            float ca = 0.f, cbv = 0.f, cc = 0.f;
+            if (tid < CO) {
+                const long bc = (long)b * CO + tid;
+                const float mu = a.mean[bc], rs = a.rstd[bc];
+                const float s1 = (float)(a.sums[2 * bc] * (double)a.inv_hw), s2 = (float)(a.sums[2 * bc + 1] * (double)a.inv_hw);
+                ca = a.relu_scale * rs;
+                cbv = -a.relu_scale * rs * rs * s2;
+                cc = a.relu_scale * (-rs * s1 + mu * rs * rs * s2);
+            }
+            cst[tid] = ca; cst[32 + tid] = cbv; cst[64 + tid] = cc;
+        }
+    }
+    __syncthreads();
+    if (tid < NDG) tile_loop<CO, CI, APPLY, NSLOT, true>(a, smem, cst);
+    else tile_loop<CO, CI, APPLY, NSLOT, false>(a, smem, cst);
+}
+
+template <int CO, int CI, bool APPLY, int NSLOT> int launch(FusedArgs a, hipStream_t s) {
+    typedef Lds<CO, CI, APPLY, NSLOT> L;
+    static_assert(L::TOTAL <= 160 * 1024, "LDS ring does not fit");
+    a.tiles_w = cdiv(a.W, TW);
+    a.tiles_h = cdiv(a.H, TH);
+#ifdef OMR_FUSED_DEBUG
+    { const char* e = getenv("OMR_FUSED_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
+    if ((long)(IH + 1) * a.W * 32 >= (1L << 30)) return OMR_ERR_UNSUPPORTED;          // 32-bit tile-relative offsets
+    auto kern = conv_bwd_fused_kernel<CO, CI, APPLY, NSLOT>;
+    static std::atomic<int> ready{0};
+    if (ready.load(std::memory_order_acquire) == 0) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL) != hipSuccess) return OMR_ERR_LAUNCH;
+        ready.store(1, std::memory_order_release);
+    }
+    const long tiles_per_img = (long)a.tiles_w * a.tiles_h;
+    long gx = (256 + a.B - 1) / a.B;                  // one workgroup per CU, split evenly over the images
+    if (gx > tiles_per_img) gx = tiles_per_img;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, 1, a.B), dim3(1024), L::TOTAL, s, a);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}
+
+template <bool APPLY> int pick(const FusedArgs& a, int CO, int CI, hipStream_t s) {
+    // ring as deep as 160 KB of LDS allows
+    if (CO == 32 && CI == 32) return launch<32, 32, APPLY, APPLY ? 2 : 3>(a, s);
+    if (CO == 32 && CI == 16) return launch<32, 16, APPLY, APPLY ? 2 : 4>(a, s);
+    if (CO == 16 && CI == 16) return launch<16, 16, APPLY, APPLY ? 4 : 6>(a, s);
+    return OMR_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int omr_conv3x3_bwd_fused(const void* g, const void* x, const void* w_flipped, void* dx, float* dw, float* db, int B, int H, int W, int CIN,
+                                     int COUT, int mask_input, float mask_scale, const void* norm_y, const float* norm_mean, const float* norm_rstd,
+                                     const void* norm_workspace, int norm_slots, int relu_mask, float relu_scale, void* stream) {
+    if (!g || !x || !w_flipped || !dx || !dw || B <= 0 || H <= 0 || W <= 0) return OMR_ERR_ARG;
+    if ((((uintptr_t)g) | ((uintptr_t)x) | ((uintptr_t)norm_y)) & 15) return OMR_ERR_UNSUPPORTED;       // tiles are fetched in 16-byte pieces
+    FusedArgs a{};
+    a.g = (const bf16*)g; a.x = (const bf16*)x; a.w = (const bf16*)w_flipped; a.dx = (bf16*)dx; a.dw = dw; a.db = db;
+    a.B = B; a.H = H; a.W = W; a.mask = mask_input; a.mask_scale = mask_scale;
+    if (norm_y) {
+        if (!norm_mean || !norm_rstd || !norm_workspace || norm_slots < 1) return OMR_ERR_ARG;
+        if (!relu_mask) return OMR_ERR_UNSUPPORTED;       // the in-LDS pass relies on (Y > 0) to keep out-of-image pixels zero
+        a.ny = (const bf16*)norm_y; a.mean = norm_mean; a.rstd = norm_rstd;
+        a.sums = (const double*)norm_workspace + (long)B * norm_slots * COUT * 2;      // the compact [B][COUT][2] sums behind the slots
+        a.inv_hw = (float)(1.0 / ((double)H * W)); a.relu_scale = relu_scale;
+        return pick<true>(a, COUT, CIN, (hipStream_t)stream);
+    }
+    return pick<false>(a, COUT, CIN, (hipStream_t)stream);
+}
+
+#ifdef OMR_FUSED_DEBUG
+extern "C" int omr_fused_prof_read(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16) != hipSuccess) return OMR_ERR_LAUNCH;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return OMR_ERR_LAUNCH; }
+    return OMR_OK;
+}
+#endif

@@ -121,10 +121,13 @@ class ConvBlock(nn.Module):
             x = Fn.Conv3x3Fn.apply(x, c1.weight, c1.bias, (1, 1), True, None, False, in_mask, in_scale, d1, False)
         s1 = 1.0 / (1.0 - d1[0]) if d1 is not None else 1.0
         d2 = self._drop() if pos == 2 else None
-        x, mean, rstd = Fn.Conv3x3Fn.apply(x, c2.weight, c2.bias, (1, 1), True, None, False, True, s1, d2, True)
+        # conv2 <- InstanceNorm <- conv3 in backward: where the one-pass conv backward exists (bf16, 16 / 32 channels), conv3 hands its
+        # un-applied gradient on and conv2's backward applies the InstanceNorm backward while it loads (functional.FUSED_BWD)
+        hand_on = bool(Fn.FUSED_BWD & 2) and torch.is_grad_enabled() and x.requires_grad and x.dtype == torch.bfloat16 and x.shape[-1] in Fn.FUSED_NORM_CHANNELS
+        x, mean, rstd = Fn.Conv3x3Fn.apply(x, c2.weight, c2.bias, (1, 1), True, None, False, True, s1, d2, True, 2 if hand_on else 0)
         s2 = 1.0 / (1.0 - d2[0]) if d2 is not None else 1.0
         d3 = self._drop() if pos == 3 else None
-        x = Fn.Conv3x3Fn.apply(x, c3.weight, c3.bias, self.stride, True, (mean, rstd), not defer_out, True, s2, d3, False)
+        x = Fn.Conv3x3Fn.apply(x, c3.weight, c3.bias, self.stride, True, (mean, rstd), not defer_out, True, s2, d3, False, 1 if hand_on else 0)
         s3 = 1.0 / (1.0 - d3[0]) if d3 is not None else 1.0
         return x, s3
 

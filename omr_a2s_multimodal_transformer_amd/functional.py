@@ -13,6 +13,7 @@ post-activation tensor, no mask is ever stored or regenerated.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -29,6 +30,20 @@ Tensor = torch.Tensor
 # InstanceNorm 1.99 -> 0.33 ms per step; step 26.7 -> 27.3 ms without the side stream) -- the data-gradient kernels are not
 # purely HBM-bound, a second pass costs almost a full one.  Kept as an option (same gradients: tests/test_round3_gpu.py).
 TWO_PASS_NORM_BWD = False
+
+# One-pass backward of the <= 32-channel stride-1 convs (csrc/conv_bwd_fused.hip; bf16): bit 1 = data + weight + bias gradient in one
+# kernel (the operands of the weight gradient are the tiles the data gradient already holds), bit 2 = the InstanceNorm backward of the
+# layer above applied while that kernel loads its tile (ConvBlock conv2 <- norm <- conv3: conv3's backward hands its un-applied
+# gradient on, conv2's backward consumes it; no omr_instnorm_bwd_apply launch, its output is never written).
+FUSED_BWD = int(os.environ.get("OMR_FUSED_BWD", "3"))
+# (at 16 channels the hand-on measures slower than the stand-alone pass: C2 step 24.66 vs 24.57 ms)
+FUSED_NORM_CHANNELS = tuple(int(c) for c in os.environ.get("OMR_FUSED_NORM_CHANNELS", "32").split(",") if c)   # conv2 widths that take the hand-on
+_PENDING_NORM = {}        # data_ptr of a handed-on gradient -> (y, mean, rstd, ws, slots, relu_mask, relu_scale); consumed by the producer conv's backward
+
+
+def clear_pending_norm() -> None:
+    """Drop hand-ons a failed backward left behind (FlatParams.zero_grad)."""
+    _PENDING_NORM.clear()
 
 
 def wt(p: Tensor, dtype: torch.dtype) -> Tensor:
@@ -60,7 +75,9 @@ class Conv3x3Fn(Function):
     InstanceNorm statistics of the (dropped) output, reduced inside the same kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, relu, in_stats, mask_own, mask_input, in_scale, drop, want_stats):
+    def forward(ctx, x, weight, bias, stride, relu, in_stats, mask_own, mask_input, in_scale, drop, want_stats, norm_bwd=0):
+        """norm_bwd: 1 = this conv normalises on load and its producer's backward applies the InstanceNorm backward (this one hands its
+        un-applied gradient on); 2 = this conv's output feeds such a consumer (its backward expects the hand-on)."""
         dt = x.dtype
         B = x.shape[0]
         cout = weight.shape[0]
@@ -74,6 +91,7 @@ class Conv3x3Fn(Function):
             note_relu(y)
         own_scale = 1.0 / (1.0 - drop[0]) if drop is not None else 1.0
         ctx.cfg = (stride, relu, mask_own, mask_input, in_scale, own_scale)
+        ctx.norm_bwd = norm_bwd
         ctx.weight, ctx.bias, ctx.stats = weight, bias, in_stats
         ctx.save_for_backward(x, y if (relu and mask_own) else None)
         if want_stats:
@@ -88,14 +106,29 @@ class Conv3x3Fn(Function):
         x, y = ctx.saved_tensors
         weight, bias, stats = ctx.weight, ctx.bias, ctx.stats
         g = gy.contiguous()
+        pend = _PENDING_NORM.pop(g.data_ptr(), None) if ctx.norm_bwd == 2 else None
+        if ctx.norm_bwd == 2 and pend is None:
+            raise RuntimeError("Conv3x3Fn: the consumer's backward did not hand on its InstanceNorm gradient")
+        one_pass = stats is None and ctx.needs_input_grad[0] and K.conv3x3_bwd_fused_ok(x, g, stride)
+        if pend is not None and not (one_pass and pend[5]):
+            # nobody to apply it on load: the stand-alone pass
+            g = K.instnorm_bwd_apply(g, pend[0], pend[1], pend[2], pend[3], pend[4], relu_mask=pend[5], relu_scale=pend[6])
+            pend = None
         if relu and mask_own:
             g = K.relu_bwd(g, y, own_scale)        # y is the stored (dropped) output: (y > 0) * 1/(1-p) is ReLU + dropout backward
+        flat = getattr(weight, "omr_flat", None)        # flipped copies are re-laid once per optimizer step (params.FlatParams.refresh_flips)
+        if one_pass and (pend is not None or FUSED_BWD & 1):
+            # one pass: data gradient (masked by the ReLU / dropout of the layer below), weight gradient, bias gradient
+            wd = flat.flipped(weight, x.dtype) if flat is not None else K.conv3x3_weight_flip(wt(weight, x.dtype))
+            if pend is not None:
+                K.instnorm_reduce_sums(pend[3], pend[4], x.shape[0], g.shape[3])
+            dx = K.conv3x3_bwd_fused(g, x, wd, weight.omr_grad, bias.omr_grad, mask_input, in_scale, norm=pend)
+            return (dx,) + (None,) * 11
         # one workgroup per CU with a full LDS ring: little can run beside it, but its ramp-up / drain overlaps the data gradient's
         # (28.37 -> 28.17 ms per C2 step; a shallower ring that leaves LDS for the neighbour loses more than it gains: 28.4)
         WgradStream.run("conv", lambda: K.conv3x3_wgrad(x, g, weight.omr_grad, stride=stride, in_stats=stats, db=bias.omr_grad), x, g, *(stats or ()))
         dx = None
         if ctx.needs_input_grad[0]:
-            flat = getattr(weight, "omr_flat", None)        # re-laid once per optimizer step (params.FlatParams.refresh_flips)
             wd = flat.flipped(weight, x.dtype) if flat is not None else K.conv3x3_weight_flip(wt(weight, x.dtype))
             H, W = x.shape[1], x.shape[2]
             if stats is None:
@@ -105,14 +138,18 @@ class Conv3x3Fn(Function):
                 # apply pass (or, TWO_PASS_NORM_BWD, the recomputing form: see the switch's comment)
                 ws, slots = K.conv_stat_ws(x.shape[0], H, W, x.shape[3], x.device)
                 kw = dict(stride=(1, 1), dil=stride, out_hw=(H, W), stat_ws=ws, stat_slots=slots, stat_x=x, stat_stats=stats)
-                if TWO_PASS_NORM_BWD:
+                if ctx.norm_bwd == 1:
+                    # the producer conv's one-pass backward applies it on load: hand on dL/dxhat with what the apply needs
+                    dx = K.conv3x3(g, wd, None, stat_mode=2, **kw)
+                    _PENDING_NORM[dx.data_ptr()] = (x, stats[0], stats[1], ws, slots, mask_input, in_scale)
+                elif TWO_PASS_NORM_BWD:
                     K.conv3x3(g, wd, None, stat_mode=4, **kw)
                     K.instnorm_reduce_sums(ws, slots, x.shape[0], x.shape[3])
                     dx = K.conv3x3(g, wd, None, stat_mode=5, relu=mask_input, mask_scale=in_scale, **kw)
                 else:
                     dxh = K.conv3x3(g, wd, None, stat_mode=2, **kw)
                     dx = K.instnorm_bwd_apply(dxh, x, stats[0], stats[1], ws, slots, relu_mask=mask_input, relu_scale=in_scale)
-        return (dx,) + (None,) * 10
+        return (dx,) + (None,) * 11
 
 
 class DwConv3x3Fn(Function):

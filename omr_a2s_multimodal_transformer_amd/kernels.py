@@ -496,6 +496,38 @@ def conv3x3_wgrad(x: Tensor, dy: Tensor, dw_phys: Tensor, stride=(1, 1), in_stat
                Ho, Wo, cur_stream())
 
 
+def conv3x3_bwd_fused_ok(x: Tensor, g: Tensor, stride=(1, 1)) -> bool:
+    """Shapes omr_conv3x3_bwd_fused covers: bf16, stride 1, (COUT, CIN) in {(32, 32), (32, 16), (16, 16)}."""
+    return (x.dtype == torch.bfloat16 and tuple(stride) == (1, 1) and x.dim() == 4 and (g.shape[-1], x.shape[-1]) in ((32, 32), (32, 16), (16, 16)))
+
+
+def conv3x3_bwd_fused(g: Tensor, x: Tensor, w_flipped: Tensor, dw_phys: Tensor, db: Optional[Tensor], mask_input: bool, mask_scale: float = 1.0,
+                      norm=None) -> Tensor:
+    """Data gradient, weight gradient and bias gradient of a stride-1 3x3 conv in one pass (bf16, <= 32 channels): returns
+    dx = conv^T(g) [* (x > 0) * mask_scale]; dw_phys / db (fp32, accumulated in place).  norm = (y, mean, rstd, ws, slots, relu_mask,
+    relu_scale): g is the gradient w.r.t. InstanceNorm(y) and the InstanceNorm backward (sums in ws, reduced by
+    instnorm_reduce_sums) + the ReLU / dropout mask of y are applied on load."""
+    require_cuda(g, x, w_flipped, dw_phys, db)
+    B, H, W, CIN = x.shape
+    COUT = g.shape[-1]
+    assert conv3x3_bwd_fused_ok(x, g) and g.shape[:3] == x.shape[:3] and g.dtype == x.dtype and g.is_contiguous() and x.is_contiguous()
+    assert tuple(w_flipped.shape) == (CIN, 3, 3, COUT) and w_flipped.dtype == x.dtype and w_flipped.is_contiguous()
+    assert dw_phys.dtype == torch.float32 and dw_phys.is_contiguous() and tuple(dw_phys.shape) == (COUT, 3, 3, CIN)
+    if db is not None:
+        assert db.dtype == torch.float32 and db.numel() == COUT
+    dx = torch.empty_like(x)
+    if norm is None:
+        ny = mean = rstd = ws = None
+        slots, relu_mask, relu_scale = 0, False, 1.0
+    else:
+        ny, mean, rstd, ws, slots, relu_mask, relu_scale = norm
+        require_cuda(ny, mean, rstd, ws)
+        assert ny.shape == g.shape and ny.is_contiguous() and ny.dtype == g.dtype and ws.dtype == torch.float64
+    lib().call("omr_conv3x3_bwd_fused", ptr(g), ptr(x), ptr(w_flipped), ptr(dx), ptr(dw_phys), ptr(db), B, H, W, CIN, COUT, int(mask_input), float(mask_scale),
+               ptr(ny), ptr(mean), ptr(rstd), ptr(ws), int(slots), int(relu_mask), float(relu_scale), cur_stream())
+    return dx
+
+
 def dwconv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor], in_stats=None, out_mask: Optional[Tensor] = None, mask_scale: float = 1.0,
               flip: bool = False) -> Tensor:
     """Depthwise 3x3 on NHWC; w is [C,9] (= [C,1,3,3] storage)."""

@@ -143,6 +143,8 @@ class FlatParams:
     def zero_grad(self) -> None:
         from .runtime import WgradStream
         WgradStream.reset()         # also drops what a failed backward pass left collected
+        from .functional import clear_pending_norm
+        clear_pending_norm()
         self.grad.zero_()
 
     def slice_of(self, names: Iterable[str]) -> Tuple[int, int]:

@@ -1,0 +1,111 @@
+"""omr_conv3x3_bwd_fused (csrc/conv_bwd_fused.hip): the one-pass backward of the <= 32-channel stride-1 convs against (i) the separate
+data-gradient / weight-gradient kernels it replaces (same bf16 inputs: data gradient bit-identical -- same MFMA order --, weight
+and bias gradients to fp32-atomic order) and (ii) torch's fp32 conv backward on the CPU (aten::convolution_backward, what
+nn.Conv2d of the reference encoder.py:132-150 runs).  Shapes include tiles that overhang the image and a one-tile image."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from omr_a2s_multimodal_transformer_amd import kernels as K  # noqa: E402
+
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def _case(B, H, W, cin, cout, seed):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn((B, H, W, cin), generator=gen).clamp_min(-0.3)            # a ReLU-like input: many exact zeros after the clamp below
+    x = torch.where(x < 0, torch.zeros_like(x), x).to(BF)
+    g = (torch.randn((B, H, W, cout), generator=gen) * 0.5).to(BF)
+    w = (torch.randn((cout, 3, 3, cin), generator=gen) * 0.2).to(BF)
+    return x, g, w
+
+
+def _torch_ref(x, g, w, mask, scale):
+    xn = x.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wn = w.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    bias = torch.zeros(w.shape[0], requires_grad=True)
+    y = F.conv2d(xn, wn, bias, padding=1)
+    y.backward(g.float().permute(0, 3, 1, 2))
+    dx = xn.grad.permute(0, 2, 3, 1)
+    if mask:
+        dx = dx * (x.float() > 0) * scale
+    return dx, wn.grad.permute(0, 2, 3, 1).contiguous(), bias.grad
+
+
+@pytest.mark.parametrize("cout,cin", [(32, 32), (32, 16), (16, 16)])
+@pytest.mark.parametrize("B,H,W", [(2, 24, 96), (1, 8, 32), (3, 13, 70)])
+@pytest.mark.parametrize("mask", [True, False])
+def test_fused_backward_matches_separate_kernels_and_torch(cout, cin, B, H, W, mask):
+    x, g, w = _case(B, H, W, cin, cout, 7 * cout + cin + H)
+    xd, gd, wd = x.to(DEV), g.to(DEV), w.to(DEV)
+    wf = K.conv3x3_weight_flip(wd)
+    scale = 1.25 if mask else 1.0
+    dw = torch.zeros((cout, 3, 3, cin), device=DEV)
+    db = torch.zeros(cout, device=DEV)
+    dx = K.conv3x3_bwd_fused(gd, xd, wf, dw, db, mask, scale)
+    # the kernels it replaces
+    dw0 = torch.zeros_like(dw)
+    db0 = torch.zeros_like(db)
+    K.conv3x3_wgrad(xd, gd, dw0, db=db0)
+    dx0 = K.conv3x3(gd, wf, None, out_hw=(H, W), out_mask=xd if mask else None, mask_scale=scale)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx0)
+    tol = 2e-3 * float(dw0.abs().max()) + 1e-4
+    assert float((dw - dw0).abs().max()) <= tol, float((dw - dw0).abs().max())
+    assert float((db - db0).abs().max()) <= 2e-3 * float(db0.abs().max()) + 1e-4
+    # torch fp32 on the same bf16-rounded operands
+    rdx, rdw, rdb = _torch_ref(x, g, w, mask, scale)
+    assert float((dx.float().cpu() - rdx).abs().max()) <= 1e-2 * float(rdx.abs().max())
+    assert float((dw.cpu() - rdw).abs().max()) <= 2e-3 * float(rdw.abs().max())
+    assert float((db.cpu() - rdb).abs().max()) <= 2e-3 * float(rdb.abs().max()) + 1e-3
+
+
+def test_fused_backward_accumulates_and_skips_null_bias():
+    x, g, w = _case(2, 16, 64, 32, 32, 5)
+    xd, gd, wf = x.to(DEV), g.to(DEV), K.conv3x3_weight_flip(w.to(DEV))
+    dw = torch.zeros((32, 3, 3, 32), device=DEV)
+    K.conv3x3_bwd_fused(gd, xd, wf, dw, None, False)
+    once = dw.clone()
+    K.conv3x3_bwd_fused(gd, xd, wf, dw, None, False)
+    torch.cuda.synchronize()
+    assert float((dw - 2 * once).abs().max()) <= 1e-3 * float(once.abs().max())
+
+
+@pytest.mark.parametrize("cout,cin", [(32, 32), (32, 16), (16, 16)])
+@pytest.mark.parametrize("B,H,W", [(2, 24, 96), (3, 13, 70)])
+def test_fused_backward_with_instancenorm_apply_on_load(cout, cin, B, H, W):
+    """norm = (...): g is dL/d(InstanceNorm(y)); the kernel forms (y > 0) * scale * InstanceNorm-backward(g) while it loads.  Against
+    omr_instnorm_bwd_apply (the stand-alone pass on the same sums) followed by the plain one-pass kernel: the data gradient within one
+    bf16 rounding of the intermediate (the fused form evaluates the same affine map with its constants folded), weight / bias
+    gradients to 2e-3."""
+    x, ghat, w = _case(B, H, W, cin, cout, 11 * cout + cin + W)
+    gen = torch.Generator().manual_seed(99)
+    y = torch.randn((B, H, W, cout), generator=gen)
+    y = torch.where(y < 0.2, torch.zeros_like(y), y).to(BF)
+    xd, gd, yd, wf = x.to(DEV), ghat.to(DEV), y.to(DEV), K.conv3x3_weight_flip(w.to(DEV))
+    mean, rstd = K.instnorm_stats(yd)
+    ws, slots = K.conv_stat_ws(B, H, W, cout, DEV)
+    xhat = (yd.float() - mean.view(B, 1, 1, cout)) * rstd.view(B, 1, 1, cout)
+    sums = torch.stack([gd.double().sum(dim=(1, 2)), (gd.float() * xhat).double().sum(dim=(1, 2))], dim=-1)      # [B, C, 2]
+    wsv = ws.view(-1)
+    wsv.zero_()
+    wsv[: B * slots * cout * 2].view(B, slots, cout, 2)[:, 0] = sums
+    K.instnorm_reduce_sums(ws, slots, B, cout)
+    scale = 1.6
+    g_ref = K.instnorm_bwd_apply(gd, yd, mean, rstd, ws, slots, True, scale)
+    dw0 = torch.zeros((cout, 3, 3, cin), device=DEV)
+    db0 = torch.zeros(cout, device=DEV)
+    dx0 = K.conv3x3_bwd_fused(g_ref, xd, wf, dw0, db0, True, 1.25)
+    dw = torch.zeros_like(dw0)
+    db = torch.zeros_like(db0)
+    dx = K.conv3x3_bwd_fused(gd, xd, wf, dw, db, True, 1.25, norm=(yd, mean, rstd, ws, slots, True, scale))
+    torch.cuda.synchronize()
+    ref = float(dx0.float().abs().max())
+    assert float((dx.float() - dx0.float()).abs().max()) <= 2e-2 * ref
+    assert float((dx.float() - dx0.float()).norm() / dx0.float().norm()) < 4e-3
+    assert float((dw - dw0).abs().max()) <= 4e-3 * float(dw0.abs().max())
+    assert float((db - db0).abs().max()) <= 4e-3 * float(db0.abs().max()) + 1e-3
+    assert torch.equal((dx == 0), (dx0 == 0)) or float(((dx == 0) != (dx0 == 0)).float().mean()) < 1e-3
