@@ -18,8 +18,8 @@
 //     permutes the source chunk instead of the destination): conflict-free for the data gradient's 16-byte row reads (16
 //     consecutive pixels, one chunk) and for the transposing ds_read_b64_tr_b16 of the weight gradient; because the swizzle
 //     depends on the column only, every address in the MFMA loops is a per-lane base + a compile-time offset;
-//   * data gradient (waves 0-7): wave w owns tile row w: D[ci][pixel], 9 taps x (CO / 16) k-steps, accumulators -> LDS staging
-//     tile -> masked 16-byte row stores;
+//   * data gradient (waves 0-7): wave w owns tile row w: D[ci][pixel], 9 taps x (CO / 16) k-steps; a lane owns a pixel and stores
+//     its masked channels straight from the accumulators;
 //   * weight gradient (waves 8-15): K = the tile's 256 pixels in 16 slabs of 16; wave w owns tap w for all slabs plus a quarter
 //     of the slabs of tap 8 (waves 0-3) or of the bias gradient = centre tap against a fragment of ones (waves 4-7): 20 MFMAs per
 //     wave and tile; its accumulators hold sums nobody else has and leave by one atomic per element per workgroup at the end;
@@ -119,11 +119,10 @@ template <int CO, int CI, bool APPLY, int NSLOT> struct Lds {
     typedef Issuer<CO, IW, NHALO> IG;
     typedef Issuer<CI, TW, NCORE> IX;
     static constexpr int DMA_PER_TILE = IG::ROUNDS * (APPLY ? 2 : 1) + IX::ROUNDS;   // instructions per issuing wave and tile
-    static constexpr int WP = (CO + 8) * 2, OPB = (CI + 8) * 2;                       // weight row / output staging pitch
+    static constexpr int WP = (CO + 8) * 2;                                           // weight row pitch
     static constexpr int GB = IG::BYTES, XB = IX::BYTES, SLOT = GB * (APPLY ? 2 : 1) + XB;
-    static constexpr int WS = 32 * 9 * WP, OS = NCORE * OPB;
-    static constexpr bool OS_IN_Y = APPLY && OS <= GB;                                // the Y tile is dead once G is formed
-    static constexpr int OFF_WS = NSLOT * SLOT, OFF_OS = OFF_WS + WS, OFF_SCRATCH = OFF_OS + (OS_IN_Y ? 0 : OS), TOTAL = OFF_SCRATCH + 1024;
+    static constexpr int WS = 32 * 9 * WP;
+    static constexpr int OFF_WS = NSLOT * SLOT, OFF_SCRATCH = OFF_WS + WS, TOTAL = OFF_SCRATCH + 1024;
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int off0, int off1, int imm) {
@@ -147,7 +146,7 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
     typedef Tile<CI> XT;
     typedef Lds<CO, CI, APPLY, NSLOT> L;
     static_assert(NSLOT >= 2 && (NSLOT - 2) * L::DMA_PER_TILE < 64, "ring depth / vmcnt range");
-    constexpr int XCPP = CI / 8, KC = CO / 16, WP = L::WP, OPB = L::OPB;
+    constexpr int XCPP = CI / 8, KC = CO / 16, WP = L::WP;
     constexpr bool WG = !DG, LD = !DG;
     const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.z;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;         // index inside the half; wave-uniform and the compiler knows it
@@ -242,7 +241,6 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
         unsigned char* Gs = smem + cur * L::SLOT;
         unsigned char* Ys = Gs + L::GB;
         unsigned char* Xt = Gs + L::GB * (APPLY ? 2 : 1);
-        unsigned char* Os = L::OS_IN_Y ? Ys : smem + L::OFF_OS;
         // this tile has landed (the DMA waves' only outstanding vector-memory operations are tile pieces, NSLOT - 2 younger tiles may
         // still be in flight); everybody is done with the slot consumed last (the previous tile's store loop)
         PROF(0);
@@ -288,15 +286,31 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
                     mma32(acc, wf, gf);
                 }
             }
-            // accumulators -> staging tile (its own LDS, or the dead Y tile)
-            unsigned char* orow = Os + (wave * TW + frow) * OPB + 8 * h;
+            // accumulators -> global memory directly: a lane owns pixel (wave, frow) and holds four runs of 4 consecutive channels
+            // (8 bytes); the four stores of a lane complete its pixel's 64-byte line within a few instructions, the ReLU mask comes from the
+            // X tile in LDS.  (Through an LDS staging tile + 16-byte row stores by all data-gradient threads -- conv3x3_mfma.h's epilogue --
+            // the tile cost one more workgroup barrier and ~1 100 cycles of serial store loop.)
+            const int oh = oh0 + wave, ow = ow0 + frow;
+            if (oh < a.H && ow < a.W && !DBG(4)) {
+                bf16* drow = DX + ((long)oh * a.W + ow) * CI + 4 * h;
+                const unsigned char* xrow = Xt + 8 * h;
 #pragma unroll
-            for (int g4 = 0; g4 < XCPP; ++g4) {
-                typedef __attribute__((ext_vector_type(4))) bf16 B4;
-                B4 o;
+                for (int g4 = 0; g4 < XCPP; ++g4) {
+                    typedef __attribute__((ext_vector_type(4))) bf16 B4;
+                    typedef __attribute__((ext_vector_type(4))) short S4;
+                    B4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[4 * g4 + e] * oscale);
-                *reinterpret_cast<B4*>(orow + 16 * g4) = o;
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[4 * g4 + e] * oscale);
+                    if (a.mask) {
+                        const S4 m = *reinterpret_cast<const S4*>(xrow + XT::chunk(wave * TW + frow, frow, g4));
+                        const S4 keep = m > (short)0;
+                        S4 bits;
+                        __builtin_memcpy(&bits, &o, sizeof(bits));
+                        bits &= keep;
+                        __builtin_memcpy(&o, &bits, sizeof(bits));
+                    }
+                    *reinterpret_cast<B4*>(drow + 8 * g4) = o;
+                }
             }
         }
         if constexpr (WG) {
@@ -324,29 +338,6 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
             quarter(std::integral_constant<int, 3>{});
         }
         PROF(4);
-        __syncthreads();                          // the staging tile is complete
-        PROF(5);
-        if constexpr (DG) {
-            // ---- masked 16-byte row stores by the data-gradient waves (the only global stores of the kernel: the DMA waves' vmcnt
-            //      must count tile pieces only)
-#pragma unroll
-            for (int j = 0; j < NCORE * XCPP / NDG; ++j) {
-                const int c = wtid + NDG * j, pl = c / XCPP, kc = c - pl * XCPP;
-                const int oh = oh0 + (pl >> 5), ow = ow0 + (pl & 31);
-                if (oh >= a.H || ow >= a.W || DBG(4)) continue;
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + pl * OPB + kc * 16);
-                if (a.mask) {
-                    typedef __attribute__((ext_vector_type(8))) short S8;
-                    const S8 m = *reinterpret_cast<const S8*>(Xt + XT::chunk(pl, pl & 31, kc));
-                    const S8 keep = m > (short)0;
-                    S8 bits;
-                    __builtin_memcpy(&bits, &v, sizeof(bits));
-                    bits &= keep;
-                    __builtin_memcpy(&v, &bits, sizeof(bits));
-                }
-                *reinterpret_cast<bf16x8*>(DX + ((long)oh * a.W + ow) * CI + kc * 8) = v;
-            }
-        }
         PROF(6);
     }
 

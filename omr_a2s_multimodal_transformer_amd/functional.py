@@ -38,6 +38,7 @@ TWO_PASS_NORM_BWD = False
 FUSED_BWD = int(os.environ.get("OMR_FUSED_BWD", "3"))
 # (at 16 channels the hand-on measures slower than the stand-alone pass: C2 step 24.66 vs 24.57 ms)
 FUSED_NORM_CHANNELS = tuple(int(c) for c in os.environ.get("OMR_FUSED_NORM_CHANNELS", "32").split(",") if c)   # conv2 widths that take the hand-on
+FUSED_MIN_COUT = int(os.environ.get("OMR_FUSED_MIN_COUT", "16"))
 _PENDING_NORM = {}        # data_ptr of a handed-on gradient -> (y, mean, rstd, ws, slots, relu_mask, relu_scale); consumed by the producer conv's backward
 
 
@@ -117,7 +118,7 @@ class Conv3x3Fn(Function):
         if relu and mask_own:
             g = K.relu_bwd(g, y, own_scale)        # y is the stored (dropped) output: (y > 0) * 1/(1-p) is ReLU + dropout backward
         flat = getattr(weight, "omr_flat", None)        # flipped copies are re-laid once per optimizer step (params.FlatParams.refresh_flips)
-        if one_pass and (pend is not None or FUSED_BWD & 1):
+        if one_pass and (pend is not None or (FUSED_BWD & 1 and g.shape[3] >= FUSED_MIN_COUT)):
             # one pass: data gradient (masked by the ReLU / dropout of the layer below), weight gradient, bias gradient
             wd = flat.flipped(weight, x.dtype) if flat is not None else K.conv3x3_weight_flip(wt(weight, x.dtype))
             if pend is not None:

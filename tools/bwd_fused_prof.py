@@ -6,7 +6,7 @@ from omr_a2s_multimodal_transformer_amd import kernels as K
 so = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omr_a2s_multimodal_transformer_amd", "libomr_hip.so"))
 B, H, W = 32, 256, 2048
 dev = "cuda"
-names = ["loop top", "dma wait", "barrier 1", "dma issue", "apply+mfma+Os", "barrier 3", "store loop"]
+names = ["loop top", "dma wait", "barrier 1", "dma issue", "apply+mfma+store", "-", "loop end"]
 for cout, cin in ((32, 32), (32, 16), (16, 16)):
     x = torch.rand((B, H, W, cin), device=dev).sub_(0.4).clamp_min_(0).to(torch.bfloat16)
     g = torch.randn((B, H, W, cout), device=dev).mul_(0.1).to(torch.bfloat16)

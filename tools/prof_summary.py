@@ -15,6 +15,7 @@ import re
 import sys
 
 FAMILIES = [      # first match wins
+    ("conv backward (one pass: dgrad + wgrad [+ norm apply])", r"conv_bwd_fused"),
     ("conv wgrad", r"wgrad_dma|conv3x3_wgrad|conv1_wgrad"),
     ("depthwise", r"dwconv"),
     ("conv fwd/dgrad", r"conv3x3_mfma|conv1_direct|conv3x3_"),
