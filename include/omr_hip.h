@@ -190,10 +190,14 @@ int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float* dw, float
  * norm_y != NULL: g is dL/d(InstanceNorm output) of the layer above and norm_y that layer's input (= this conv's stored output);
  * the InstanceNorm backward (omr_instnorm_bwd_apply's arithmetic, sums from norm_workspace after omr_instnorm_reduce_sums)
  * and the ReLU / dropout mask of norm_y are applied while the tile is loaded, so the gradient w.r.t. this conv's output never
- * exists in memory.  OMR_ERR_UNSUPPORTED for other shapes (callers then use omr_conv3x3_fwd + omr_conv3x3_wgrad). */
+ * exists in memory.  x_mean / x_rstd != NULL (CIN = COUT = 16): the conv normalised its input on load; xhat = (x - mean) * rstd is
+ * formed in LDS for the weight gradient and dx = dL/dxhat leaves with {sum dx, sum dx * xhat} reduced into the slots of
+ * stat_workspace (omr_conv3x3_fwd stat_mode 2's layout: omr_instnorm_bwd_apply or the norm_y form above consumes them).
+ * OMR_ERR_UNSUPPORTED for other shapes (callers then use omr_conv3x3_fwd + omr_conv3x3_wgrad). */
 int omr_conv3x3_bwd_fused(const void* g, const void* x, const void* w_flipped, void* dx, float* dw, float* db, int B, int H, int W, int CIN,
                           int COUT, int mask_input, float mask_scale, const void* norm_y, const float* norm_mean, const float* norm_rstd,
-                          const void* norm_workspace, int norm_slots, int relu_mask, float relu_scale, void* stream);
+                          const void* norm_workspace, int norm_slots, int relu_mask, float relu_scale, const float* x_mean, const float* x_rstd,
+                          void* stat_workspace, int stat_slots, void* stream);
 /* depthwise 3x3, stride 1, pad 1 (DepthSepConv2D.depth_conv, encoder.py:56-64); flip=1 mirrors the taps (data gradient) */
 int omr_dwconv3x3(int dtype, const void* x, const void* w, const float* bias, void* y, const float* in_mean, const float* in_rstd,
                   const void* out_mask, float mask_scale, int B, int H, int W, int C, int flip, void* stream);

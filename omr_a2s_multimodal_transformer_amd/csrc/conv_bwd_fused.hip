@@ -27,6 +27,9 @@
 //     G = (Y > 0) * relu_scale * rstd * (Ghat - mean(Ghat) - yhat * mean(Ghat * yhat)),   yhat = (Y - mean) * rstd,
 //     computed in LDS from the Ghat and Y halo tiles the ring delivers (an in-place pass before the MFMAs): the stand-alone
 //     apply pass (norm.hip), its output and both re-reads of it go.
+//   * XN (16 channels): the conv normalises its input on load (ConvBlock conv3): the X tile is normalised in LDS -- xhat is the weight
+//     gradient's operand -- and the data gradient dL/dxhat leaves with {sum dx, sum dx * xhat} reduced deterministically into the
+//     InstanceNorm-backward slots (what conv3x3_mfma.h's stat_mode 2 epilogue does for the separate data-gradient kernel).
 #include <atomic>
 #include <type_traits>
 #include "omr_common.h"
@@ -90,6 +93,7 @@ template <int CB, int IWT, int NPIXT> struct Issuer {
 struct FusedArgs {
     const bf16* g; const bf16* x; const bf16* w; bf16* dx; float* dw; float* db;
     const bf16* ny; const float* mean; const float* rstd; const double* sums; float inv_hw; float relu_scale;
+    const float* xmean; const float* xrstd; double* stat_ws; int stat_slots;      // XN: normalise X in LDS, reduce {sum dx, sum dx * xhat}
     int B, H, W, tiles_w, tiles_h, mask; float mask_scale;
 #ifdef OMR_FUSED_DEBUG
     int dbg = 0;      // bring-up ablations (OMR_FUSED_DBG=bits): 1 no data-gradient MFMAs, 2 no weight-gradient MFMAs, 4 no stores, 8 no DMA
@@ -140,7 +144,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int off0, i
 //   * issuing the DMA behind the MFMAs, beside the store loop: 1 097 / 1 288 us;
 //   * register-staged tiles, two 8-wave workgroups per CU (the conv3x3_mfma.h pipeline): 1 042 us plain, but the apply needs the
 //     second tensor in staging registers too and spills at 128 registers.
-template <int CO, int CI, bool APPLY, int NSLOT, bool DG>
+template <int CO, int CI, bool APPLY, bool XN, int NSLOT, bool DG>
 __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* smem, const float* cst) {
     typedef Tile<CO> GT;
     typedef Tile<CI> XT;
@@ -225,6 +229,10 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
     const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
 
     const float oscale = a.mask ? a.mask_scale : 1.f;
+    constexpr int NSV = XN ? XCPP * 4 : 1;                  // XN, DG: partial sums of this lane's channels 8 g4 + 4 h + e
+    float ssum[NSV], ssq[NSV];
+#pragma unroll
+    for (int e = 0; e < NSV; ++e) ssum[e] = ssq[e] = 0.f;
 #ifdef OMR_FUSED_DEBUG
     unsigned long long prof_t = __builtin_readcyclecounter();
 #endif
@@ -268,8 +276,23 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
                 }
                 *reinterpret_cast<bf16x8*>(Gs + off) = v;
             }
-            __syncthreads();
         }
+        if constexpr (XN) {
+            // xhat = x * rstd - mean * rstd in place over the X tile (pixels of an overhanging tile stay 0)
+            constexpr int NXCH = NCORE * XCPP;
+            static_assert(NXCH <= 1024, "one chunk per thread");
+            if (tid < NXCH) {
+                const int pix = tid / XCPP, k = tid % XCPP;
+                if (oh0 + (pix >> 5) < a.H && ow0 + (pix & 31) < a.W) {
+                    unsigned char* px = Xt + XT::chunk(pix, pix & 31, k);
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(px);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16)fmaf((float)v[e], cst[k * 8 + e], cst[32 + k * 8 + e]);
+                    *reinterpret_cast<bf16x8*>(px) = v;
+                }
+            }
+        }
+        if constexpr (APPLY || XN) __syncthreads();
 
         if constexpr (DG) {
             // ---- data gradient: D[ci][pixel] for tile row `wave`
@@ -310,6 +333,11 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
                         __builtin_memcpy(&o, &bits, sizeof(bits));
                     }
                     *reinterpret_cast<B4*>(drow + 8 * g4) = o;
+                    if constexpr (XN) {      // InstanceNorm-backward sums over the stored values (conv3x3_mfma.h stat_mode 2)
+                        const B4 xh = *reinterpret_cast<const B4*>(xrow + XT::chunk(wave * TW + frow, frow, g4));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float f = (float)o[e]; ssum[4 * g4 + e] += f; ssq[4 * g4 + e] += f * (float)xh[e]; }
+                    }
                 }
             }
         }
@@ -342,6 +370,32 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
     }
 
     if constexpr (LD) dma_drain();        // the trailing dummy DMA must not outlive the workgroup's LDS
+    if constexpr (XN) {
+        // DETERMINISTIC reduction of the sums (conv3x3_mfma.h's protocol: fixed-order fp64 sum of the block's partials, plain store into
+        // the block's own slot stat_ws[b][blockIdx.x][CI][2]; slots no block owns are zeroed by block 0)
+        float* red = reinterpret_cast<float*>(smem);          // [2][CI][256]: the ring is dead
+        __syncthreads();
+        if constexpr (DG) {
+            const int j = wave * 32 + frow;
+#pragma unroll
+            for (int g4 = 0; g4 < XCPP; ++g4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 8 * g4 + 4 * h + e;
+                    red[c * 256 + j] = ssum[4 * g4 + e];
+                    red[(CI + c) * 256 + j] = ssq[4 * g4 + e];
+                }
+        }
+        __syncthreads();
+        if (DG && tid < 2 * CI) {
+            const int k = tid / CI, c = tid - k * CI;
+            double acc2 = 0.0;
+            for (int j = 0; j < 256; ++j) acc2 += (double)red[(k * CI + c) * 256 + j];
+            a.stat_ws[(((long)b * a.stat_slots + blockIdx.x) * CI + c) * 2 + k] = acc2;
+            if (blockIdx.x == 0)
+                for (int sl = gridDim.x; sl < a.stat_slots; ++sl) a.stat_ws[(((long)b * a.stat_slots + sl) * CI + c) * 2 + k] = 0.0;
+        }
+    }
     if constexpr (WG) {
         // ---- the workgroup's weight-gradient sums: one atomic per element (tap 8 and the bias arrive in four quarters)
 #pragma unroll
@@ -364,7 +418,7 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
     }
 }
 
-template <int CO, int CI, bool APPLY, int NSLOT>
+template <int CO, int CI, bool APPLY, bool XN, int NSLOT>
 __global__ __launch_bounds__(1024) void conv_bwd_fused_kernel(FusedArgs a) {
     typedef Lds<CO, CI, APPLY, NSLOT> L;
     constexpr int GCPP = CO / 8, WP = L::WP;
@@ -392,12 +446,19 @@ __global__ __launch_bounds__(1024) void conv_bwd_fused_kernel(FusedArgs a) {
             cst[tid] = ca; cst[32 + tid] = cbv; cst[64 + tid] = cc;
         }
     }
+    if constexpr (XN) {
+        static_assert(!APPLY, "one set of constants");
+        if (tid < 32) {
+            const float rs = tid < CI ? a.xrstd[(long)b * CI + tid] : 0.f, mu = tid < CI ? a.xmean[(long)b * CI + tid] : 0.f;
+            cst[tid] = rs; cst[32 + tid] = -mu * rs;
+        }
+    }
     __syncthreads();
-    if (tid < NDG) tile_loop<CO, CI, APPLY, NSLOT, true>(a, smem, cst);
-    else tile_loop<CO, CI, APPLY, NSLOT, false>(a, smem, cst);
+    if (tid < NDG) tile_loop<CO, CI, APPLY, XN, NSLOT, true>(a, smem, cst);
+    else tile_loop<CO, CI, APPLY, XN, NSLOT, false>(a, smem, cst);
 }
 
-template <int CO, int CI, bool APPLY, int NSLOT> int launch(FusedArgs a, hipStream_t s) {
+template <int CO, int CI, bool APPLY, bool XN, int NSLOT> int launch(FusedArgs a, hipStream_t s) {
     typedef Lds<CO, CI, APPLY, NSLOT> L;
     static_assert(L::TOTAL <= 160 * 1024, "LDS ring does not fit");
     a.tiles_w = cdiv(a.W, TW);
@@ -406,7 +467,7 @@ template <int CO, int CI, bool APPLY, int NSLOT> int launch(FusedArgs a, hipStre
     { const char* e = getenv("OMR_FUSED_DBG"); a.dbg = e ? atoi(e) : 0; }
 #endif
     if ((long)(IH + 1) * a.W * 32 >= (1L << 30)) return OMR_ERR_UNSUPPORTED;          // 32-bit tile-relative offsets
-    auto kern = conv_bwd_fused_kernel<CO, CI, APPLY, NSLOT>;
+    auto kern = conv_bwd_fused_kernel<CO, CI, APPLY, XN, NSLOT>;
     static std::atomic<int> ready{0};
     if (ready.load(std::memory_order_acquire) == 0) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL) != hipSuccess) return OMR_ERR_LAUNCH;
@@ -415,6 +476,7 @@ template <int CO, int CI, bool APPLY, int NSLOT> int launch(FusedArgs a, hipStre
     const long tiles_per_img = (long)a.tiles_w * a.tiles_h;
     long gx = (256 + a.B - 1) / a.B;                  // one workgroup per CU, split evenly over the images
     if (gx > tiles_per_img) gx = tiles_per_img;
+    if (XN && gx > a.stat_slots) gx = a.stat_slots;          // one workspace slot per block of an image
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, 1, a.B), dim3(1024), L::TOTAL, s, a);
     OMR_CHECK_LAUNCH();
@@ -423,9 +485,9 @@ template <int CO, int CI, bool APPLY, int NSLOT> int launch(FusedArgs a, hipStre
 
 template <bool APPLY> int pick(const FusedArgs& a, int CO, int CI, hipStream_t s) {
     // ring as deep as 160 KB of LDS allows
-    if (CO == 32 && CI == 32) return launch<32, 32, APPLY, APPLY ? 2 : 3>(a, s);
-    if (CO == 32 && CI == 16) return launch<32, 16, APPLY, APPLY ? 2 : 4>(a, s);
-    if (CO == 16 && CI == 16) return launch<16, 16, APPLY, APPLY ? 4 : 6>(a, s);
+    if (CO == 32 && CI == 32) return launch<32, 32, APPLY, false, APPLY ? 2 : 3>(a, s);
+    if (CO == 32 && CI == 16) return launch<32, 16, APPLY, false, APPLY ? 2 : 4>(a, s);
+    if (CO == 16 && CI == 16) return launch<16, 16, APPLY, false, APPLY ? 4 : 6>(a, s);
     return OMR_ERR_UNSUPPORTED;
 }
 
@@ -433,12 +495,22 @@ template <bool APPLY> int pick(const FusedArgs& a, int CO, int CI, hipStream_t s
 
 extern "C" int omr_conv3x3_bwd_fused(const void* g, const void* x, const void* w_flipped, void* dx, float* dw, float* db, int B, int H, int W, int CIN,
                                      int COUT, int mask_input, float mask_scale, const void* norm_y, const float* norm_mean, const float* norm_rstd,
-                                     const void* norm_workspace, int norm_slots, int relu_mask, float relu_scale, void* stream) {
+                                     const void* norm_workspace, int norm_slots, int relu_mask, float relu_scale, const float* x_mean,
+                                     const float* x_rstd, void* stat_workspace, int stat_slots, void* stream) {
     if (!g || !x || !w_flipped || !dx || !dw || B <= 0 || H <= 0 || W <= 0) return OMR_ERR_ARG;
+    if ((x_mean != nullptr) != (x_rstd != nullptr) || (x_mean != nullptr) != (stat_workspace != nullptr)) return OMR_ERR_ARG;
     if ((((uintptr_t)g) | ((uintptr_t)x) | ((uintptr_t)norm_y)) & 15) return OMR_ERR_UNSUPPORTED;       // tiles are fetched in 16-byte pieces
     FusedArgs a{};
     a.g = (const bf16*)g; a.x = (const bf16*)x; a.w = (const bf16*)w_flipped; a.dx = (bf16*)dx; a.dw = dw; a.db = db;
     a.B = B; a.H = H; a.W = W; a.mask = mask_input; a.mask_scale = mask_scale;
+    if (x_mean) {
+        // the conv normalises its input on load (ConvBlock conv3, stride 1): xhat feeds the weight gradient, and the data gradient
+        // dL/dxhat leaves with the InstanceNorm-backward sums reduced into the slots (omr_conv3x3_fwd stat_mode 2's protocol)
+        if (norm_y || mask_input || stat_slots < 1) return OMR_ERR_ARG;
+        if (COUT != 16 || CIN != 16) return OMR_ERR_UNSUPPORTED;
+        a.xmean = x_mean; a.xrstd = x_rstd; a.stat_ws = (double*)stat_workspace; a.stat_slots = stat_slots;
+        return launch<16, 16, false, true, 6>(a, (hipStream_t)stream);
+    }
     if (norm_y) {
         if (!norm_mean || !norm_rstd || !norm_workspace || norm_slots < 1) return OMR_ERR_ARG;
         if (!relu_mask) return OMR_ERR_UNSUPPORTED;       // the in-LDS pass relies on (Y > 0) to keep out-of-image pixels zero

@@ -502,11 +502,12 @@ def conv3x3_bwd_fused_ok(x: Tensor, g: Tensor, stride=(1, 1)) -> bool:
 
 
 def conv3x3_bwd_fused(g: Tensor, x: Tensor, w_flipped: Tensor, dw_phys: Tensor, db: Optional[Tensor], mask_input: bool, mask_scale: float = 1.0,
-                      norm=None) -> Tensor:
+                      norm=None, xnorm=None) -> Tensor:
     """Data gradient, weight gradient and bias gradient of a stride-1 3x3 conv in one pass (bf16, <= 32 channels): returns
     dx = conv^T(g) [* (x > 0) * mask_scale]; dw_phys / db (fp32, accumulated in place).  norm = (y, mean, rstd, ws, slots, relu_mask,
     relu_scale): g is the gradient w.r.t. InstanceNorm(y) and the InstanceNorm backward (sums in ws, reduced by
-    instnorm_reduce_sums) + the ReLU / dropout mask of y are applied on load."""
+    instnorm_reduce_sums) + the ReLU / dropout mask of y are applied on load.  xnorm = (mean, rstd, ws, slots) (16 -> 16 channels): the
+    conv normalised x on load; returns dL/dxhat and fills the InstanceNorm-backward slots of ws (conv_stat_ws layout)."""
     require_cuda(g, x, w_flipped, dw_phys, db)
     B, H, W, CIN = x.shape
     COUT = g.shape[-1]
@@ -523,8 +524,14 @@ def conv3x3_bwd_fused(g: Tensor, x: Tensor, w_flipped: Tensor, dw_phys: Tensor, 
         ny, mean, rstd, ws, slots, relu_mask, relu_scale = norm
         require_cuda(ny, mean, rstd, ws)
         assert ny.shape == g.shape and ny.is_contiguous() and ny.dtype == g.dtype and ws.dtype == torch.float64
+    xm = xr = xws = None
+    xslots = 0
+    if xnorm is not None:
+        xm, xr, xws, xslots = xnorm
+        require_cuda(xm, xr, xws)
+        assert xws.dtype == torch.float64 and norm is None and not mask_input
     lib().call("omr_conv3x3_bwd_fused", ptr(g), ptr(x), ptr(w_flipped), ptr(dx), ptr(dw_phys), ptr(db), B, H, W, CIN, COUT, int(mask_input), float(mask_scale),
-               ptr(ny), ptr(mean), ptr(rstd), ptr(ws), int(slots), int(relu_mask), float(relu_scale), cur_stream())
+               ptr(ny), ptr(mean), ptr(rstd), ptr(ws), int(slots), int(relu_mask), float(relu_scale), ptr(xm), ptr(xr), ptr(xws), int(xslots), cur_stream())
     return dx
 
 

@@ -109,3 +109,36 @@ def test_fused_backward_with_instancenorm_apply_on_load(cout, cin, B, H, W):
     assert float((dw - dw0).abs().max()) <= 4e-3 * float(dw0.abs().max())
     assert float((db - db0).abs().max()) <= 4e-3 * float(db0.abs().max()) + 1e-3
     assert torch.equal((dx == 0), (dx0 == 0)) or float(((dx == 0) != (dx0 == 0)).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 24, 96), (3, 13, 70), (1, 8, 32)])
+def test_fused_backward_of_the_normalise_on_load_conv(B, H, W):
+    """xnorm = (...): ConvBlock 0's conv3 (16 -> 16, InstanceNorm applied on load).  Against the separate kernels: omr_conv3x3_fwd
+    stat_mode 2 (data gradient + InstanceNorm-backward sums) and omr_conv3x3_wgrad with in_stats: data gradient bit-identical, the sums
+    (after the slot reduction) to 3e-3 of the largest -- the one-pass form multiplies by the bf16 xhat it holds in LDS, the separate kernel by the
+    fp32 one --, weight / bias gradients to 4e-3 (same reason), and the apply pass on either workspace gives the same gradient."""
+    c = 16
+    x, g, w = _case(B, H, W, c, c, 1000 + H)
+    xd, gd, wf = x.to(DEV), g.to(DEV), K.conv3x3_weight_flip(w.to(DEV))
+    mean, rstd = K.instnorm_stats(xd)
+    ws0, slots = K.conv_stat_ws(B, H, W, c, DEV)
+    dx0 = K.conv3x3(gd, wf, None, out_hw=(H, W), stat_mode=2, stat_ws=ws0, stat_slots=slots, stat_x=xd, stat_stats=(mean, rstd))
+    dw0 = torch.zeros((c, 3, 3, c), device=DEV)
+    db0 = torch.zeros(c, device=DEV)
+    K.conv3x3_wgrad(xd, gd, dw0, in_stats=(mean, rstd), db=db0)
+    ws, _ = K.conv_stat_ws(B, H, W, c, DEV)
+    ws.view(-1).fill_(123.0)                          # every slot must be written
+    dw = torch.zeros_like(dw0)
+    db = torch.zeros_like(db0)
+    dx = K.conv3x3_bwd_fused(gd, xd, wf, dw, db, False, 1.0, xnorm=(mean, rstd, ws, slots))
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx0)
+    a0 = K.instnorm_bwd_apply(dx0, xd, mean, rstd, ws0, slots, True, 1.3)
+    a1 = K.instnorm_bwd_apply(dx, xd, mean, rstd, ws, slots, True, 1.3)
+    torch.cuda.synchronize()
+    n = B * slots * c * 2
+    s0, s1 = ws0.view(-1)[n:n + B * c * 2], ws.view(-1)[n:n + B * c * 2]      # the compact sums the apply pass left behind the slots
+    assert float((s0 - s1).abs().max()) <= 3e-3 * float(s0.abs().max()) + 1e-6, (float((s0 - s1).abs().max()), float(s0.abs().max()))
+    assert float((a0.float() - a1.float()).abs().max()) <= 1e-2 * float(a0.float().abs().max())
+    assert float((dw - dw0).abs().max()) <= 4e-3 * float(dw0.abs().max())
+    assert float((db - db0).abs().max()) <= 2e-3 * float(db0.abs().max()) + 1e-4
