@@ -73,19 +73,27 @@ template <int CB, int IWT, int NPIXT> struct Issuer {
             rel[r] = L < NCH ? (il * Wimg + jl) * CB + c * 8 : -1;
         }
     }
+    // Interior tiles (tile-uniform, the common case) take a straight-line path: one 64-bit add and one select per round -- the issue
+    // code runs on waves that have MFMAs waiting, every instruction of it is on the tile's critical path.
     __device__ __forceinline__ void issue(const bf16* origin, int y0, int x0, int Himg, int Wimg, bool interior, unsigned lds_base, unsigned scratch,
                                           int wtid) const {
         const bf16* zsrc = reinterpret_cast<const bf16*>(&g_zero_line);
+        if (interior) {
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            bool ok = rel[r] >= 0;
-            if (!interior) {
-                const int ih = y0 + (ij[r] & 0xffff), iw = x0 + (ij[r] >> 16);
-                ok = ok && (unsigned)ih < (unsigned)Himg && (unsigned)iw < (unsigned)Wimg;
+            for (int r = 0; r < ROUNDS; ++r) {
+                const bf16* src = rel[r] >= 0 ? origin + rel[r] : zsrc;
+                const int L0 = r * NLD + (wtid & ~63);
+                dma16(src, L0 < WINS * 64 ? lds_base + (unsigned)L0 * 16u : scratch);
             }
-            const bf16* src = ok ? origin + rel[r] : zsrc;
-            const int L0 = r * NLD + (wtid & ~63);
-            dma16(src, L0 < WINS * 64 ? lds_base + (unsigned)L0 * 16u : scratch);
+        } else {
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const int ih = y0 + (ij[r] & 0xffff), iw = x0 + (ij[r] >> 16);
+                const bool ok = rel[r] >= 0 && (unsigned)ih < (unsigned)Himg && (unsigned)iw < (unsigned)Wimg;
+                const bf16* src = ok ? origin + rel[r] : zsrc;
+                const int L0 = r * NLD + (wtid & ~63);
+                dma16(src, L0 < WINS * 64 ? lds_base + (unsigned)L0 * 16u : scratch);
+            }
         }
     }
 };
@@ -202,16 +210,22 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
     for (int kw = 0; kw < 3; ++kw) doff[kw] = GT::chunk(wave * IW + frow + kw, frow + kw, h);
     const int woff = frow * 9 * WP + h * 16;                 // DG: weight fragment, row ci = frow, k half h
     const int q = (lane & 15) >> 2, p = lane & 3, cb = (lane >> 4) & 1;
-    // WG: wave w owns tap w for all 16 pixel slabs; its second accumulator takes a quarter of the slabs of tap 8 (waves 0-3) or of the
+    // WG: wave w owns tap w for all pixel slabs (16 of 16 pixels; PAIR: 8 of 32); its second accumulator takes a quarter of the slabs of tap 8 (waves 0-3) or of the
     // bias sums = centre tap against ones (waves 4-7): 20 MFMAs per wave and tile (the data-gradient waves: 18).  (Two taps x half the
     // slabs per wave -- one X fragment for both, 448 transposing reads per tile instead of 576 -- needs a third accumulator: spills.)
     const bool third_bias = wave >= 4;
     const bool third = !third_bias || a.db != nullptr;
     const int third_q = wave & 3;
+    // 16 x 16 channels (PAIR): the cb = 1 half of the wave would only feed rows / columns >= 16 of the 32 x 32 product, which nobody wants.
+    // It takes the NEXT 16 pixels of the tile row instead, same 16 channels: the product becomes block diagonal -- D[0:16][0:16] sums
+    // pixels k0 .. k0+15, D[16:32][16:32] sums k0+16 .. k0+31 -- so one MFMA and one pair of LDS reads cover a whole tile row (half the
+    // reads, half the MFMAs: conv_wgrad_dma.hip's trick); the flush adds the two diagonal blocks.
+    constexpr bool PAIR = CO == 16 && CI == 16;
+    constexpr int NSLAB = PAIR ? 8 : 16;                     // pixel slabs per tile
     int xo[2], go[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int col = 8 * h + q + 4 * u;
+        const int col = 8 * h + q + 4 * u + (PAIR ? 16 * cb : 0);
         xo[u] = XT::tr(col, col, cb, p);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -348,9 +362,10 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
                 constexpr int QUARTER = decltype(quarter_c)::value;
                 constexpr bool T3 = decltype(with_third)::value;
 #pragma unroll
-                for (int s4 = 0; s4 < (DBG(2) ? 0 : 4); ++s4) {
-                    const int s = QUARTER * 4 + s4;
-                    const int ximm = ((s >> 1) * TW + (s & 1) * 16) * XT::PITCH, gimm = ((s >> 1) * IW + (s & 1) * 16) * GT::PITCH;
+                for (int s4 = 0; s4 < (DBG(2) ? 0 : NSLAB / 4); ++s4) {
+                    const int s = QUARTER * (NSLAB / 4) + s4;
+                    const int srow = PAIR ? s : s >> 1, scol = PAIR ? 0 : (s & 1) * 16;
+                    const int ximm = (srow * TW + scol) * XT::PITCH, gimm = (srow * IW + scol) * GT::PITCH;
                     const bf16x8 xf = tr_frag(Xt, xo[0], xo[1], ximm);
                     mma32(wacc[0], tr_frag(Gs, go[0][0], go[0][1], gimm), xf);
                     if constexpr (T3) mma32(wacc[1], tr_frag(Gs, go[1][0], go[1][1], gimm), third_bias ? ones : xf);
@@ -405,14 +420,16 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = acc_row(r, lane), ci = lane & 31;
-                if (co < CO && ci < CI) atomicAdd(&a.dw[((long)co * 9 + tw8) * CI + ci], wacc[j][r]);
+                if constexpr (PAIR) {
+                    if ((co < 16) == (ci < 16)) atomicAdd(&a.dw[((long)(co & 15) * 9 + tw8) * CI + (ci & 15)], wacc[j][r]);
+                } else if (co < CO && ci < CI) atomicAdd(&a.dw[((long)co * 9 + tw8) * CI + ci], wacc[j][r]);
             }
         }
         if (third_bias && a.db != nullptr && (lane & 31) == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = acc_row(r, lane);
-                if (co < CO) atomicAdd(&a.db[co], wacc[1][r]);
+                if (PAIR || co < CO) atomicAdd(&a.db[co & (PAIR ? 15 : 31)], wacc[1][r]);       // PAIR: rows 16-31 hold the second pixel half
             }
         }
     }

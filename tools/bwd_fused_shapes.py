@@ -47,3 +47,17 @@ for cout, cin in ((32, 32), (32, 16), (16, 16)):
         t_p = timed(lambda: K.instnorm_bwd_apply(g, y, mean, rstd, ws, slots, True, 1.1))
         print(f"    apply-on-load fused {t_a:7.1f} us   vs apply pass {t_p:7.1f} + dgrad + wgrad = {t_p + t_d + t_w:7.1f} us", flush=True)
     del x, g, dw
+
+# the normalise-on-load form (16 -> 16): against omr_conv3x3_fwd stat_mode 2 + omr_conv3x3_wgrad with in_stats
+x = torch.rand((B, H, W, 16), device=dev).sub_(0.4).clamp_min_(0).to(torch.bfloat16)
+g = torch.randn((B, H, W, 16), device=dev).mul_(0.1).to(torch.bfloat16)
+w = (torch.rand((16, 3, 3, 16), device=dev) - 0.5).to(torch.bfloat16)
+wf = K.conv3x3_weight_flip(w)
+dw = torch.zeros((16, 3, 3, 16), device=dev)
+db = torch.zeros(16, device=dev)
+mean, rstd = K.instnorm_stats(x)
+ws, slots = K.conv_stat_ws(B, H, W, 16, dev)
+t_f = timed(lambda: K.conv3x3_bwd_fused(g, x, wf, dw, db, False, 1.0, xnorm=(mean, rstd, ws, slots)))
+t_d = timed(lambda: K.conv3x3(g, wf, None, out_hw=(H, W), stat_mode=2, stat_ws=ws, stat_slots=slots, stat_x=x, stat_stats=(mean, rstd)))
+t_w = timed(lambda: K.conv3x3_wgrad(x, g, dw, in_stats=(mean, rstd), db=db))
+print(f"normalise-on-load 16 -> 16: fused {t_f:7.1f} us   dgrad + sums {t_d:7.1f} + wgrad {t_w:7.1f} = {t_d + t_w:7.1f} us", flush=True)
