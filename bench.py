@@ -355,8 +355,9 @@ def roofline_others(B, H, W, T, d, nhead):
     timed live at the step's own shapes (HIP events on the launch stream; the library launches on torch's current stream):
     cross-attention forward / backward (one decoder layer's: B x 4 heads x 512 queries x 4096 memory keys, dropout + key bias as
     in training; MFMA-eligible work 4*T*S*d*B flops forward, 2.5x that backward), InstanceNorm backward apply on the largest map
-    (32 channels at full resolution: 2 reads + 1 write), the 64-channel conv weight gradient (conv_blocks.2.conv2: 18*64*64 flops
-    per pixel; also 2 tensor reads)."""
+    (32 channels at full resolution: 2 reads + 1 write; the step itself no longer runs it on that map), the one-pass backward of the
+    32-channel full-resolution conv that replaced it (3 reads + 1 write), the 64-channel conv weight gradient (conv_blocks.2.conv2:
+    18*64*64 flops per pixel; also 2 tensor reads)."""
     from omr_a2s_multimodal_transformer_amd import kernels as K
     dev, bf = torch.device("cuda"), torch.bfloat16
     S = tokens_of((H, W))
@@ -388,7 +389,19 @@ def roofline_others(B, H, W, T, d, nhead):
     nb = 3.0 * B * H * W * C * 2
     res.append({"kernel": "instnorm_bwd_apply_kernel (conv_blocks.1: 32 channels at full resolution)", "bound": "hbm", "avg_launch_ms": round(ms, 4),
                 "algorithmic_bytes": nb, "achieved": round(nb / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb / ms / 1e6 / HBM_PEAK_GBS, 4)})
-    del x, g
+    # the one-pass backward of conv_blocks.1.conv2 (32 -> 32 channels at full resolution) with the InstanceNorm backward applied on
+    # load: reads dL/dxhat, the norm's input and the conv's input once, writes the data gradient once (weight / bias gradients are 37 KB)
+    y = torch.rand((B, H, W, C), device=dev).sub_(0.4).clamp_min_(0).to(bf)
+    wf = K.conv3x3_weight_flip((torch.rand((C, 3, 3, C), device=dev) - 0.5).to(bf))
+    dw = torch.zeros((C, 3, 3, C), device=dev)
+    db = torch.zeros(C, device=dev)
+    K.instnorm_reduce_sums(ws, slots, B, C)
+    ms = _timed(lambda: K.conv3x3_bwd_fused(g, x, wf, dw, db, True, 1.0, norm=(y, mean, rstd, ws, slots, True, 1.0)))
+    nb = 4.0 * B * H * W * C * 2
+    res.append({"kernel": "conv_bwd_fused_kernel<32,32,apply> (conv_blocks.1.conv2: data + weight + bias gradient, InstanceNorm backward on load)",
+                "bound": "hbm", "avg_launch_ms": round(ms, 4), "algorithmic_bytes": nb, "algorithmic_flops": 2 * 18.0 * C * C * B * H * W,
+                "achieved": round(nb / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb / ms / 1e6 / HBM_PEAK_GBS, 4)})
+    del x, g, y
     C, h2, w2 = 64, H // 2, W // 2
     x = torch.rand((B, h2, w2, C), device=dev).to(bf)
     dy = torch.rand((B, h2, w2, C), device=dev).to(bf)
