@@ -12,8 +12,9 @@
 // One 16-wave workgroup per CU, persistent over the 8 x 32 tiles of ONE image (grid z = image):
 //   * operand tiles travel global -> LDS asynchronously (global_load_lds_dwordx4, dma_common.h) into a ring of 2-6 slots: the
 //     next one to five tiles (G halo 10 x 34 pixels + X tile each; 53-97 KB) are in flight behind the current tile's math, no staging
-//     registers; out-of-image pixels are fetched from a line of zeros.  Only waves 8-15 issue DMA and they issue nothing else
-//     that counts in vmcnt, so "tile landed" is an exact s_waitcnt; only waves 0-7 store to global memory.
+//     registers; out-of-image pixels are fetched from a line of zeros.  Both halves of the workgroup issue DMA (waves 8-15 the G halo,
+//     waves 0-7 the X tile / Y halo) and every wave's count of vector-memory operations per tile is a compile-time constant -- the
+//     data-gradient lanes of pixels outside the image store to a sink -- so "my pieces of this tile have landed" is an exact s_waitcnt.
 //   * LDS tiles are dense pixel-major rows with the 16-byte chunk index XORed by a function of the pixel's COLUMN (the DMA
 //     permutes the source chunk instead of the destination): conflict-free for the data gradient's 16-byte row reads (16
 //     consecutive pixels, one chunk) and for the transposing ds_read_b64_tr_b16 of the weight gradient; because the swizzle
@@ -44,6 +45,7 @@ constexpr int NDG = 512, NWG = 512;           // threads of the data-gradient / 
 constexpr int NLD = NWG;                      // the weight-gradient waves also issue the DMA
 
 __device__ uint4 g_zero_line;                 // 16 zero bytes: the DMA source of every out-of-image chunk
+__device__ uint4 g_store_sink[4];             // where the data-gradient lanes of pixels outside the image store (every lane always stores: exact vmcnt)
 
 template <int CB> struct Tile {               // dense pixel-major LDS tile with CB channels; all offsets in bytes
     static constexpr int CPP = CB / 8, PITCH = CB * 2;
@@ -130,7 +132,8 @@ __device__ unsigned long long g_prof[2][8];
 template <int CO, int CI, bool APPLY, int NSLOT> struct Lds {
     typedef Issuer<CO, IW, NHALO> IG;
     typedef Issuer<CI, TW, NCORE> IX;
-    static constexpr int DMA_PER_TILE = IG::ROUNDS * (APPLY ? 2 : 1) + IX::ROUNDS;   // instructions per issuing wave and tile
+    // DMA instructions per wave and tile: the weight-gradient waves fetch the G halo, the data-gradient waves the X tile (and the Y halo)
+    static constexpr int DPT_WG = IG::ROUNDS, DPT_DG = IX::ROUNDS + (APPLY ? IG::ROUNDS : 0);
     static constexpr int WP = (CO + 8) * 2;                                           // weight row pitch
     static constexpr int GB = IG::BYTES, XB = IX::BYTES, SLOT = GB * (APPLY ? 2 : 1) + XB;
     static constexpr int WS = 32 * 9 * WP;
@@ -157,9 +160,13 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
     typedef Tile<CO> GT;
     typedef Tile<CI> XT;
     typedef Lds<CO, CI, APPLY, NSLOT> L;
-    static_assert(NSLOT >= 2 && (NSLOT - 2) * L::DMA_PER_TILE < 64, "ring depth / vmcnt range");
     constexpr int XCPP = CI / 8, KC = CO / 16, WP = L::WP;
-    constexpr bool WG = !DG, LD = !DG;
+    constexpr bool WG = !DG;
+    // vector-memory operations a wave may still have in flight when its pieces of the CURRENT tile must have landed: the younger tiles'
+    // pieces and, on the data-gradient waves, the XCPP stores of each of the NSLOT - 1 tiles finished since this tile was requested
+    // (every lane always stores -- pixels outside the image go to a sink --, so the count is exact)
+    constexpr int VM_ALLOWED = DG ? (NSLOT - 2) * L::DPT_DG + (NSLOT - 1) * XCPP : (NSLOT - 2) * L::DPT_WG;
+    static_assert(NSLOT >= 2 && VM_ALLOWED < 64, "ring depth / vmcnt range");
     const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.z;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;         // index inside the half; wave-uniform and the compiler knows it
     const int wtid = tid & 511;
@@ -172,10 +179,11 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
     const bf16* X = a.x + (long)b * a.H * a.W * CI;
     bf16* DX = a.dx + (long)b * a.H * a.W * CI;
 
-    // ---- loaders: DMA descriptors (the Y halo shares the G halo's)
+    // ---- DMA descriptors (the Y halo shares the G halo's)
     typename L::IG ig;
     typename L::IX ix;
-    if constexpr (LD) { ig.init(a.W, wtid); ix.init(a.W, wtid); }
+    if constexpr (WG || APPLY) ig.init(a.W, wtid);
+    if constexpr (DG) ix.init(a.W, wtid);
     const int tiles_per_img = a.tiles_h * a.tiles_w;
     const int step_h = (int)gridDim.x / a.tiles_w, step_w = (int)gridDim.x - step_h * a.tiles_w;      // tile (th, tw) -> the block's next tile
     auto advance = [&](int& th, int& tw) {
@@ -190,9 +198,18 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
         const bool in_x = live && oh0 + TH <= a.H && ow0 + TW <= a.W;
         const unsigned base = lds0 + (unsigned)(slot * L::SLOT), scratch = lds0 + (unsigned)L::OFF_SCRATCH;
         const long og = ((long)(oh0 - 1) * a.W + (ow0 - 1)) * CO, ox = ((long)oh0 * a.W + ow0) * CI;
-        ig.issue(G + og, oh0 - 1, ow0 - 1, a.H, a.W, in_g, base, scratch, wtid);
-        if constexpr (APPLY) ig.issue(NY + og, oh0 - 1, ow0 - 1, a.H, a.W, in_g, base + (unsigned)L::GB, scratch, wtid);
-        ix.issue(X + ox, oh0, ow0, a.H, a.W, in_x, base + (unsigned)(L::GB * (APPLY ? 2 : 1)), scratch, wtid);
+        if constexpr (WG) ig.issue(G + og, oh0 - 1, ow0 - 1, a.H, a.W, in_g, base, scratch, wtid);
+        if constexpr (DG && APPLY) ig.issue(NY + og, oh0 - 1, ow0 - 1, a.H, a.W, in_g, base + (unsigned)L::GB, scratch, wtid);
+        if constexpr (DG) ix.issue(X + ox, oh0, ow0, a.H, a.W, in_x, base + (unsigned)(L::GB * (APPLY ? 2 : 1)), scratch, wtid);
+    };
+    bf16* const sink = reinterpret_cast<bf16*>(g_store_sink) + 4 * (lane >> 5);
+    auto dummy_stores = [&]() {                  // XCPP stores to the sink: keeps the data-gradient waves' in-flight count in its steady state
+        if constexpr (DG) {
+            typedef __attribute__((ext_vector_type(4))) bf16 B4;
+            const B4 z = {0, 0, 0, 0};
+#pragma unroll
+            for (int g4 = 0; g4 < XCPP; ++g4) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(sink), "v"(z) : "memory");
+        }
     };
 
     // ---- APPLY: this thread's channel chunk of the in-LDS pass is fixed (1024 % CPP == 0): its constants live in registers
@@ -251,11 +268,9 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
     unsigned long long prof_t = __builtin_readcyclecounter();
 #endif
     int th = (int)blockIdx.x / a.tiles_w, tw = (int)blockIdx.x - th * a.tiles_w;       // this block's first tile
-    int ith = th, itw = tw;                                                          // loaders: the next tile to request
-    if constexpr (LD) {
+    int ith = th, itw = tw;                                                          // the next tile to request
 #pragma unroll
-        for (int st = 0; st < NSLOT - 1; ++st) { issue(ith, itw, st); advance(ith, itw); }
-    }
+    for (int st = 0; st < NSLOT - 1; ++st) { issue(ith, itw, st); advance(ith, itw); dummy_stores(); }
     int cur = 0;
 
     for (; th < a.tiles_h; advance(th, tw), cur = cur + 1 == NSLOT ? 0 : cur + 1) {
@@ -266,12 +281,13 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
         // this tile has landed (the DMA waves' only outstanding vector-memory operations are tile pieces, NSLOT - 2 younger tiles may
         // still be in flight); everybody is done with the slot consumed last (the previous tile's store loop)
         PROF(0);
-        if constexpr (LD) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSLOT - 2) * L::DMA_PER_TILE) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM_ALLOWED) : "memory");
         PROF(1);
         __syncthreads();
         PROF(2);
         // (issuing after the MFMAs instead, beside the other half's store loop, was measured: 1076 -> 1097 us, 1212 -> 1288 us with two slots)
-        if constexpr (LD) { issue(ith, itw, cur == 0 ? NSLOT - 1 : cur - 1); advance(ith, itw); }
+        issue(ith, itw, cur == 0 ? NSLOT - 1 : cur - 1);
+        advance(ith, itw);
         PROF(3);
         if constexpr (APPLY) {
             // G = cA * Ghat + cB * Y + cC where Y > 0, else 0 (out-of-image pixels arrive as Y = 0), in place over Ghat
@@ -328,30 +344,31 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
             // X tile in LDS.  (Through an LDS staging tile + 16-byte row stores by all data-gradient threads -- conv3x3_mfma.h's epilogue --
             // the tile cost one more workgroup barrier and ~1 100 cycles of serial store loop.)
             const int oh = oh0 + wave, ow = ow0 + frow;
-            if (oh < a.H && ow < a.W && !DBG(4)) {
-                bf16* drow = DX + ((long)oh * a.W + ow) * CI + 4 * h;
-                const unsigned char* xrow = Xt + 8 * h;
+            const bool inside = oh < a.H && ow < a.W;
+            bf16* drow = inside ? DX + ((long)oh * a.W + ow) * CI + 4 * h : sink;
+            const int dstep = inside ? 8 : 0;
+            const unsigned char* xrow = Xt + 8 * h;
 #pragma unroll
-                for (int g4 = 0; g4 < XCPP; ++g4) {
-                    typedef __attribute__((ext_vector_type(4))) bf16 B4;
-                    typedef __attribute__((ext_vector_type(4))) short S4;
-                    B4 o;
+            for (int g4 = 0; g4 < XCPP; ++g4) {
+                typedef __attribute__((ext_vector_type(4))) bf16 B4;
+                typedef __attribute__((ext_vector_type(4))) short S4;
+                B4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[4 * g4 + e] * oscale);
-                    if (a.mask) {
-                        const S4 m = *reinterpret_cast<const S4*>(xrow + XT::chunk(wave * TW + frow, frow, g4));
-                        const S4 keep = m > (short)0;
-                        S4 bits;
-                        __builtin_memcpy(&bits, &o, sizeof(bits));
-                        bits &= keep;
-                        __builtin_memcpy(&o, &bits, sizeof(bits));
-                    }
-                    *reinterpret_cast<B4*>(drow + 8 * g4) = o;
-                    if constexpr (XN) {      // InstanceNorm-backward sums over the stored values (conv3x3_mfma.h stat_mode 2)
-                        const B4 xh = *reinterpret_cast<const B4*>(xrow + XT::chunk(wave * TW + frow, frow, g4));
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[4 * g4 + e] * oscale);
+                if (a.mask) {
+                    const S4 m = *reinterpret_cast<const S4*>(xrow + XT::chunk(wave * TW + frow, frow, g4));
+                    const S4 keep = m > (short)0;
+                    S4 bits;
+                    __builtin_memcpy(&bits, &o, sizeof(bits));
+                    bits &= keep;
+                    __builtin_memcpy(&o, &bits, sizeof(bits));
+                }
+                // (asm: the store must be ONE instruction per run whatever the compiler thinks of the addresses -- the waits count them)
+                asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(drow + dstep * g4), "v"(o) : "memory");
+                if constexpr (XN) {      // InstanceNorm-backward sums over the stored values (conv3x3_mfma.h stat_mode 2)
+                    const B4 xh = *reinterpret_cast<const B4*>(xrow + XT::chunk(wave * TW + frow, frow, g4));
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { const float f = (float)o[e]; ssum[4 * g4 + e] += f; ssq[4 * g4 + e] += f * (float)xh[e]; }
-                    }
+                    for (int e = 0; e < 4; ++e) { const float f = inside ? (float)o[e] : 0.f; ssum[4 * g4 + e] += f; ssq[4 * g4 + e] += f * (float)xh[e]; }
                 }
             }
         }
@@ -384,7 +401,7 @@ __device__ __forceinline__ void tile_loop(const FusedArgs& a, unsigned char* sme
         PROF(6);
     }
 
-    if constexpr (LD) dma_drain();        // the trailing dummy DMA must not outlive the workgroup's LDS
+    dma_drain();        // the trailing dummy DMA must not outlive the workgroup's LDS
     if constexpr (XN) {
         // DETERMINISTIC reduction of the sums (conv3x3_mfma.h's protocol: fixed-order fp64 sum of the block's partials, plain store into
         // the block's own slot stat_ws[b][blockIdx.x][CI][2]; slots no block owns are zeroed by block 0)
