@@ -415,6 +415,95 @@ __global__ __launch_bounds__(192) void conv1_wgrad_kernel(const T* __restrict__ 
     if (db) for (int i = threadIdx.x; i < COUT; i += blockDim.x) atomicAdd(&db[i], red[COUT * 9 + i]);
 }
 
+// The same weight gradient on the MFMA (bf16, 16 output channels: the benchmark's first layer; the last kernel of a backward pass, so
+// its whole duration sits in front of the optimizer):  D[n][tap] += dY^T[n][pixels] . P[pixels][tap]  with K = 16 consecutive pixels of
+// an image row per MFMA, P the im2col of the 1-channel image -- column `tap` of P is the image row shifted by the tap, so a lane's
+// fragment (8 consecutive pixels of one tap) is one aligned 16-byte read from one of THREE copies of the image halo tile kept in LDS,
+// pre-shifted by 0 / 1 / 2 pixels.  Column 9 of P is all ones: D[n][9] is the bias gradient.  dY^T comes out of the pixel-major dY
+// tile with ds_read_b64_tr_b16 (lanes 16-31 of a half repeat lanes 0-15: rows 16-31 of D are a copy nobody stores).
+// Workgroup = 4 waves on a tile of 8 rows x 32 pixels (a wave: two rows = four MFMAs); persistent over the tiles of its share; LDS is
+// 10 KB, so a CU holds many workgroups and their load -> LDS -> MFMA phases overlap without a software pipeline.
+typedef __attribute__((address_space(3))) bf16x4 C1LdsV4;
+__global__ __launch_bounds__(256) void conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ dw,
+                                                                float* __restrict__ db, int B, int H, int Wd, int tiles_h, int tiles_w) {
+    constexpr int TH1 = 8, TW1 = 32, IH1 = TH1 + 2, XP = 40;               // XP: row pitch of the shifted image copies (elements; 80 B)
+    __shared__ __attribute__((aligned(16))) bf16 Ys[TH1 * TW1 * 16];        // dY tile, pixel-major 32-byte rows, chunk index ^ (col >> 3) & 1
+    __shared__ __attribute__((aligned(16))) bf16 Xs[3][IH1][XP];            // Xs[s][r][c] = image(tile row r - 1, tile col c - 1 + s), zero outside
+    __shared__ float red[4][16][10];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = (lane & 15) >> 2, p = lane & 3, hh = lane >> 5, ntap = lane & 31;
+    const int kh = ntap / 3, kw = ntap - 3 * kh;                             // valid for ntap < 9
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int ntiles = B * tiles_h * tiles_w;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / (tiles_h * tiles_w), rem = tile - b * tiles_h * tiles_w;
+        const int th = rem / tiles_w, tw = rem - th * tiles_w, oh0 = th * TH1, ow0 = tw * TW1;
+        // global -> registers: two 16-byte dY chunks per thread (pixel tid / 2 + 128 j, chunk tid % 2), image halo values
+        bf16x8 gv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pix = (tid >> 1) + 128 * j, oh = oh0 + (pix >> 5), ow = ow0 + (pix & 31);
+            gv[j] = zero8;
+            if (oh < H && ow < Wd) gv[j] = *reinterpret_cast<const bf16x8*>(dy + (((long)b * H + oh) * Wd + ow) * 16 + (tid & 1) * 8);
+        }
+        bf16 xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                  // shifted copies: 3 x 10 x 32 = 960 values
+            const int e = tid + 256 * j, sft = e / (IH1 * TW1), r = (e / TW1) % IH1, c = e % TW1;
+            const int ih = oh0 - 1 + r, iw = ow0 - 1 + c + sft;
+            xv[j] = (bf16)0.f;
+            if (e < 3 * IH1 * TW1 && ih >= 0 && ih < H && iw >= 0 && iw < Wd) xv[j] = x[((long)b * H + ih) * Wd + iw];
+        }
+        __syncthreads();                               // the previous tile's MFMAs are done with the LDS tiles
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pix = (tid >> 1) + 128 * j;
+            *reinterpret_cast<bf16x8*>(Ys + pix * 16 + (((tid & 1) ^ ((pix >> 3) & 1)) << 3)) = gv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j, sft = e / (IH1 * TW1), r = (e / TW1) % IH1, c = e % TW1;
+            if (e < 3 * IH1 * TW1) Xs[sft][r][c] = xv[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int row = wave * 2 + (s4 >> 1), col0 = (s4 & 1) * 16;
+            // A: dY^T, lane (q, p, hh) addresses pixel col0 + 8 hh + q (+4), channels 4 p .. 4 p + 3 (both 16-lane groups of a half the same)
+            const int pa = row * TW1 + col0 + 8 * hh + q;
+            const int offa = pa * 16 + ((((p >> 1) ^ (((pa & 31) >> 3) & 1)) << 3) | ((p & 1) << 2));
+            const int pb = pa + 4;
+            const int offb = pb * 16 + ((((p >> 1) ^ (((pb & 31) >> 3) & 1)) << 3) | ((p & 1) << 2));
+            const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((C1LdsV4*)(Ys + offa));
+            const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((C1LdsV4*)(Ys + offb));
+            const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            // B: column ntap of the im2col: pixels (row + kh - 1, col0 + 8 hh + 0..7 + kw - 1) = copy kw, tile row row + kh, columns col0 + 8 hh ..
+            bf16x8 bfr = ntap == 9 ? ones : zero8;
+            if (ntap < 9) bfr = *reinterpret_cast<const bf16x8*>(&Xs[kw][row + kh][col0 + 8 * hh]);
+            mma32(acc, af, bfr);
+        }
+    }
+    // D[n][tap]: column = lane & 31 = tap, row(reg) = channel; fold the four waves through LDS, one atomic per value per workgroup
+    if (ntap < 10) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = acc_row(r, lane);
+            if (n < 16) red[wave][n][ntap] = acc[r];
+        }
+    }
+    __syncthreads();
+    if (tid < 160) {
+        const int n = tid / 10, t = tid - n * 10;
+        const float v = red[0][n][t] + red[1][n][t] + red[2][n][t] + red[3][n][t];
+        if (t < 9) atomicAdd(&dw[n * 9 + t], v);
+        else if (db) atomicAdd(&db[n], v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Depthwise 3x3, stride 1, pad 1 on NHWC (DepthSepConv2D.depth_conv, encoder.py:56-64).  One thread =
 // one pixel x VEC channels.  flip=1 applies the taps mirrored (data gradient).  Optional fused
@@ -961,6 +1050,14 @@ extern "C" int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float
         if (stride_h != 1 || stride_w != 1 || in_mean) return OMR_ERR_UNSUPPORTED;
         int gy = B * H; if (gy > 64) gy = 64;      // few, long-lived blocks: each ends with 10 COUT atomics onto the same five cache lines
         dim3 grid(cdiv(W, 64), gy);
+        if (dtype == OMR_BF16 && COUT == 16 && (((uintptr_t)dy) & 15) == 0) {
+            const int th = cdiv(H, 8), tw = cdiv(W, 32);
+            long nt = (long)B * th * tw;
+            const int nblk = (int)(nt < 256 * 6 ? nt : 256 * 6);           // persistent: each workgroup ends with 160 atomics onto the same cache lines
+            hipLaunchKernelGGL(conv1_wgrad_mfma_kernel, dim3(nblk), dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, dw, db, B, H, W, th, tw);
+            OMR_CHECK_LAUNCH();
+            return OMR_OK;
+        }
         DISPATCH_T(dtype, {
             if (COUT == 16) hipLaunchKernelGGL((conv1_wgrad_kernel<T, 16>), grid, 192, 0, s, (const T*)x, (const T*)dy, dw, db, B, H, W);
             else if (COUT == 32) hipLaunchKernelGGL((conv1_wgrad_kernel<T, 32>), grid, 192, 0, s, (const T*)x, (const T*)dy, dw, db, B, H, W);
