@@ -37,8 +37,7 @@ TWO_PASS_NORM_BWD = False
 # gradient on, conv2's backward consumes it; no omr_instnorm_bwd_apply launch, its output is never written), bit 4 = the one-pass form
 # of the 16-channel normalise-on-load conv (ConvBlock 0's conv3).
 FUSED_BWD = int(os.environ.get("OMR_FUSED_BWD", "7"))
-# (at 16 channels the hand-on measures slower than the stand-alone pass: C2 step 24.66 vs 24.57 ms)
-FUSED_NORM_CHANNELS = tuple(int(c) for c in os.environ.get("OMR_FUSED_NORM_CHANNELS", "32").split(",") if c)   # conv2 widths that take the hand-on
+FUSED_NORM_CHANNELS = tuple(int(c) for c in os.environ.get("OMR_FUSED_NORM_CHANNELS", "16,32").split(",") if c)   # conv2 widths that take the hand-on
 FUSED_MIN_COUT = int(os.environ.get("OMR_FUSED_MIN_COUT", "16"))
 _PENDING_NORM = {}        # data_ptr of a handed-on gradient -> (y, mean, rstd, ws, slots, relu_mask, relu_scale); consumed by the producer conv's backward
 
@@ -128,7 +127,7 @@ class Conv3x3Fn(Function):
             return (dx,) + (None,) * 11
         # the normalise-on-load conv of the 16-channel block (stride 1): its one-pass form also normalises x in LDS and reduces the
         # InstanceNorm-backward sums
-        one_pass_norm = (bool(FUSED_BWD & 4) and stats is not None and ctx.needs_input_grad[0] and ctx.norm_bwd != 1 and tuple(stride) == (1, 1)
+        one_pass_norm = (bool(FUSED_BWD & 4) and stats is not None and ctx.needs_input_grad[0] and tuple(stride) == (1, 1)
                          and x.shape[-1] == 16 and g.shape[-1] == 16 and K.conv3x3_bwd_fused_ok(x, g, stride))
         # one workgroup per CU with a full LDS ring: little can run beside it, but its ramp-up / drain overlaps the data gradient's
         # (28.37 -> 28.17 ms per C2 step; a shallower ring that leaves LDS for the neighbour loses more than it gains: 28.4)
@@ -145,13 +144,17 @@ class Conv3x3Fn(Function):
                 # apply pass (or, TWO_PASS_NORM_BWD, the recomputing form: see the switch's comment)
                 ws, slots = K.conv_stat_ws(x.shape[0], H, W, x.shape[3], x.device)
                 kw = dict(stride=(1, 1), dil=stride, out_hw=(H, W), stat_ws=ws, stat_slots=slots, stat_x=x, stat_stats=stats)
-                if ctx.norm_bwd == 1:
-                    # the producer conv's one-pass backward applies it on load: hand on dL/dxhat with what the apply needs
-                    dx = K.conv3x3(g, wd, None, stat_mode=2, **kw)
-                    _PENDING_NORM[dx.data_ptr()] = (x, stats[0], stats[1], ws, slots, mask_input, in_scale)
-                elif one_pass_norm:
-                    dxh = K.conv3x3_bwd_fused(g, x, wd, weight.omr_grad, bias.omr_grad, False, 1.0, xnorm=(stats[0], stats[1], ws, slots))
-                    dx = K.instnorm_bwd_apply(dxh, x, stats[0], stats[1], ws, slots, relu_mask=mask_input, relu_scale=in_scale)
+                if ctx.norm_bwd == 1 or one_pass_norm:
+                    if one_pass_norm:
+                        dxh = K.conv3x3_bwd_fused(g, x, wd, weight.omr_grad, bias.omr_grad, False, 1.0, xnorm=(stats[0], stats[1], ws, slots))
+                    else:
+                        dxh = K.conv3x3(g, wd, None, stat_mode=2, **kw)
+                    if ctx.norm_bwd == 1:
+                        # the producer conv's one-pass backward applies it on load: hand on dL/dxhat with what the apply needs
+                        dx = dxh
+                        _PENDING_NORM[dx.data_ptr()] = (x, stats[0], stats[1], ws, slots, mask_input, in_scale)
+                    else:
+                        dx = K.instnorm_bwd_apply(dxh, x, stats[0], stats[1], ws, slots, relu_mask=mask_input, relu_scale=in_scale)
                 elif TWO_PASS_NORM_BWD:
                     K.conv3x3(g, wd, None, stat_mode=4, **kw)
                     K.instnorm_reduce_sums(ws, slots, x.shape[0], x.shape[3])
