@@ -242,11 +242,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a, const uint
     constexpr int PK = HD + VEC;          // Ks pitch
     constexpr int PV = BST + 4;   // Vt pitch: 136 B (bf16) / 272 B (fp32) -> conflict-free permuted reads
     constexpr float THR = 8.f;            // the reference maximum of a row moves when a tile exceeds it by 2^THR
-    __shared__ __attribute__((aligned(16))) T Ks[BST * PK];
     constexpr bool TRD = std::is_same<T, bf16>::value;          // bf16: V is staged row-major and read with tr reads
+    // bf16, query-per-wave form: the staged tiles are DOUBLE-BUFFERED -- tile t+1 is committed to the other buffer before the math on
+    // tile t, so one workgroup barrier per tile orders both "t+1 is complete" and "everybody is done with t" (was two)
+    constexpr int NBUF = (TRD && !SPLITW) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) T Ks_[NBUF][BST * PK];
     __shared__ __attribute__((aligned(16))) T Vt[TRD ? 8 : HD * PV];
-    __shared__ __attribute__((aligned(16))) T Vs[TRD ? BST * PK : 8];
-    __shared__ __attribute__((aligned(16))) F Ka[BST + 1];      // augmented k-step, key side: the key bias; entry BST = zeros
+    __shared__ __attribute__((aligned(16))) T Vs_[NBUF][TRD ? BST * PK : 8];
+    __shared__ __attribute__((aligned(16))) F Ka_[NBUF][BST + 1];      // augmented k-step, key side: the key bias; entry BST = zeros
 
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -299,16 +302,39 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a, const uint
         vt.load(V, a.ldv, kvb, a.S, tid);
         if (tid < BST) bias_r = a.key_bias ? a.key_bias[(long)b * a.S + min(kvb + tid, a.S - 1)] * LOG2E : 0.f;     // keys >= S: masked
     };
-    if (tid == 0) Ka[BST] = frag_zero<T>();
-    if (kv_beg < kv_end) prefetch(kv_beg);
-    for (int kvb = kv_beg; kvb < kv_end; kvb += BST) {
-        __syncthreads();
-        kt.template store<PK>(Ks, tid);
-        if constexpr (TRD) vt.template store<PK>(Vs, tid);
+    if (tid < NBUF) Ka_[tid][BST] = frag_zero<T>();
+    auto commit = [&](int buf) {
+        kt.template store<PK>(Ks_[buf], tid);
+        if constexpr (TRD) vt.template store<PK>(Vs_[buf], tid);
         else vt.template store_t<PV>(Vt, tid);
-        if (tid < BST) Ka[tid] = Aug<T>::x(bias_r);
+        if (tid < BST) Ka_[buf][tid] = Aug<T>::x(bias_r);
+    };
+    if (kv_beg < kv_end) prefetch(kv_beg);
+    if constexpr (NBUF == 2) {
+        if (kv_beg < kv_end) {
+            commit(0);
+            if (kv_beg + BST < kv_end) prefetch(kv_beg + BST);
+        }
         __syncthreads();
-        if (kvb + BST < kv_end) prefetch(kvb + BST);
+    }
+    int buf = 0;
+    for (int kvb = kv_beg; kvb < kv_end; kvb += BST) {
+        if constexpr (NBUF == 2) {
+            // tile kvb sits complete in buffer `buf` (the barrier that ended the previous iteration); the next tile's registers go into
+            // the other buffer, which everybody left at that barrier, and the loads of the tile after it start
+            if (kvb + BST < kv_end) {
+                commit(buf ^ 1);
+                if (kvb + 2 * BST < kv_end) prefetch(kvb + 2 * BST);
+            }
+        } else {
+            __syncthreads();
+            commit(0);
+            __syncthreads();
+            if (kvb + BST < kv_end) prefetch(kvb + BST);
+        }
+        T* const Ks = Ks_[buf];
+        T* const Vs = Vs_[buf];
+        F* const Ka = Ka_[buf];
         const int kv0 = kvb + kboff;                            // first key of this wave's 64-key tile
         const uint64_t* wp = DROP ? dmask + drop_word_base(a, b * a.H + h, qw0 >> 5, min(kv0, a.S - 1) >> 6) : nullptr;
 
@@ -405,13 +431,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a, const uint
                     mma32(acc_o[d], vf, pf);
                 }
             }
+        if constexpr (NBUF == 2) { __syncthreads(); buf ^= 1; }
     }
     float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     float m_fin = l_tot > 0.f ? m_ref : -INFINITY;              // a row that saw no finite score has no reference
     if constexpr (SPLITW) {
         // merge the four waves' partial softmaxes of the same 32 query rows (log2 domain): the staging tiles are dead
         __syncthreads();
-        float* o_s = reinterpret_cast<float*>(Ks);              // [4][HD][32]
+        float* o_s = reinterpret_cast<float*>(Ks_[0]);              // [4][HD][32]
         float* m_s = o_s + 4 * HD * 32;                         // [4][32]
         float* l_s = m_s + 4 * 32;
         static_assert((4 * HD * 32 + 8 * 32) * sizeof(float) <= sizeof(T) * BST * PK, "merge scratch fits in the K tile");
@@ -514,11 +541,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a, const u
     constexpr int NKS = HD / KS, NDB = HD / 32, BKV = 64;
     constexpr int PK = HD + VEC;
     constexpr int PV = BKV + 4;
-    __shared__ __attribute__((aligned(16))) T Ks[BKV * PK];
-    __shared__ __attribute__((aligned(16))) T Vs[BKV * PK];
     constexpr bool TRD = std::is_same<T, bf16>::value;          // bf16: K^T fragments are tr reads of the row-major Ks tile
+    constexpr int NBUF = TRD ? 2 : 1;                           // bf16: double-buffered tiles, one workgroup barrier per tile (see the forward)
+    __shared__ __attribute__((aligned(16))) T Ks_[NBUF][BKV * PK];
+    __shared__ __attribute__((aligned(16))) T Vs_[NBUF][BKV * PK];
     __shared__ __attribute__((aligned(16))) T Kt[TRD ? 8 : HD * PV];
-    __shared__ __attribute__((aligned(16))) F Ka[BKV + 1];      // augmented k-step, key side: the key bias; entry BKV = zeros
+    __shared__ __attribute__((aligned(16))) F Ka_[NBUF][BKV + 1];      // augmented k-step, key side: the key bias; entry BKV = zeros
 
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -573,16 +601,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a, const u
         vt.load(V, a.ldv, kv0, a.S, tid);
         if (tid < BKV) bias_r = a.key_bias ? a.key_bias[(long)b * a.S + min(kv0 + tid, a.S - 1)] * LOG2E : 0.f;     // keys >= S: masked
     };
-    if (tid == 0) Ka[BKV] = frag_zero<T>();
-    if (kv_beg < kv_end) prefetch(kv_beg);
-    for (int kv0 = kv_beg; kv0 < kv_end; kv0 += BKV) {
-        __syncthreads();
-        kt.template store<PK>(Ks, tid);
-        vt.template store<PK>(Vs, tid);
+    if (tid < NBUF) Ka_[tid][BKV] = frag_zero<T>();
+    auto commit = [&](int bi) {
+        kt.template store<PK>(Ks_[bi], tid);
+        vt.template store<PK>(Vs_[bi], tid);
         if constexpr (!TRD) kt.template store_t<PV>(Kt, tid);
-        if (tid < BKV) Ka[tid] = Aug<T>::x(bias_r);
+        if (tid < BKV) Ka_[bi][tid] = Aug<T>::x(bias_r);
+    };
+    if (kv_beg < kv_end) prefetch(kv_beg);
+    if constexpr (NBUF == 2) {
+        if (kv_beg < kv_end) {
+            commit(0);
+            if (kv_beg + BKV < kv_end) prefetch(kv_beg + BKV);
+        }
         __syncthreads();
-        if (kv0 + BKV < kv_end) prefetch(kv0 + BKV);
+    }
+    int buf = 0;
+    for (int kv0 = kv_beg; kv0 < kv_end; kv0 += BKV) {
+        if constexpr (NBUF == 2) {
+            if (kv0 + BKV < kv_end) {
+                commit(buf ^ 1);
+                if (kv0 + 2 * BKV < kv_end) prefetch(kv0 + 2 * BKV);
+            }
+        } else {
+            __syncthreads();
+            commit(0);
+            __syncthreads();
+            if (kv0 + BKV < kv_end) prefetch(kv0 + BKV);
+        }
+        T* const Ks = Ks_[buf];
+        T* const Vs = Vs_[buf];
+        F* const Ka = Ka_[buf];
         const bool full = (kv0 + BKV <= a.S) && (qw0 + 32 <= a.T) && lq < 0 &&
                           (!a.causal || (kv0 + BKV - 1 <= qw0 && (!win_on || kv0 >= qw0 + 31 - a.window)));
         const uint64_t* wp = DROP ? dmask + drop_word_base(a, b * a.H + h, qw0 >> 5, kv0 >> 6) : nullptr;
@@ -677,6 +726,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a, const u
                 }
             }
         }
+        if constexpr (NBUF == 2) { __syncthreads(); buf ^= 1; }
     }
     const float osc = a.scale * a.drop_scale;
     if (q < a.T) {
@@ -721,14 +771,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a, const 
     constexpr int NKS = HD / KS, NDB = HD / 32, BQ = 64;
     constexpr int PK = HD + VEC;
     constexpr int PT = BQ + 4;   // transposed tiles [d][q]
-    __shared__ __attribute__((aligned(16))) T Qs[BQ * PK];
-    __shared__ __attribute__((aligned(16))) T Ds[BQ * PK];
     constexpr bool TRD = std::is_same<T, bf16>::value;          // bf16: Q^T / dO^T fragments are tr reads of Qs / Ds
+    constexpr int NBUF = TRD ? 2 : 1;                           // bf16: double-buffered tiles, one workgroup barrier per tile (see the forward)
+    __shared__ __attribute__((aligned(16))) T Qs_[NBUF][BQ * PK];
+    __shared__ __attribute__((aligned(16))) T Ds_[NBUF][BQ * PK];
     __shared__ __attribute__((aligned(16))) T Qt[TRD ? 8 : HD * PT];
     __shared__ __attribute__((aligned(16))) T Dt[TRD ? 8 : HD * PT];
-    __shared__ __attribute__((aligned(16))) F Qa[BQ + 1];       // augmented k-step, query side of the score chain: -lse; entry BQ = zeros
-    __shared__ __attribute__((aligned(16))) F Da[BQ + 1];       // ... of the dP chain: -delta / c
-    __shared__ __attribute__((aligned(16))) float ndc_s[BQ];    // -delta / c per query row (the value a dropped score takes)
+    __shared__ __attribute__((aligned(16))) F Qa_[NBUF][BQ + 1];       // augmented k-step, query side of the score chain: -lse; entry BQ = zeros
+    __shared__ __attribute__((aligned(16))) F Da_[NBUF][BQ + 1];       // ... of the dP chain: -delta / c
+    __shared__ __attribute__((aligned(16))) float ndc_s_[NBUF][BQ];    // -delta / c per query row (the value a dropped score takes)
 
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -787,25 +838,50 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a, const 
             ndc_r = -a.delta[sbase + qq] / a.drop_scale;
         }
     };
-    if (tid == 0) { Qa[BQ] = frag_zero<T>(); Da[BQ] = frag_zero<T>(); }
-    if (q_beg < q_end) prefetch(q_beg);
-    for (int q0 = q_beg; q0 < q_end; q0 += BQ) {
-        __syncthreads();
-        qt.template store<PK>(Qs, tid);
-        dt.template store<PK>(Ds, tid);
+    if (tid < NBUF) { Qa_[tid][BQ] = frag_zero<T>(); Da_[tid][BQ] = frag_zero<T>(); }
+    auto commit = [&](int bi) {
+        qt.template store<PK>(Qs_[bi], tid);
+        dt.template store<PK>(Ds_[bi], tid);
         if constexpr (!TRD) {
             qt.template store_t<PT>(Qt, tid);
             dt.template store_t<PT>(Dt, tid);
         }
-        if (tid < BQ) { Qa[tid] = Aug<T>::x(-lse_r); Da[tid] = Aug<T>::x(ndc_r); ndc_s[tid] = ndc_r; }
-        __syncthreads();
-        uint32_t wbits[BQ / 32];
-#pragma unroll
-        for (int mb = 0; mb < BQ / 32; ++mb) {                  // requested ahead of the next tile's rows: vmcnt is in order
-            const int qb32 = min((q0 >> 5) + mb, nqb32 - 1);
-            wbits[mb] = DROP ? wcol[qb32 * wq_stride] >> (4 * hh) : 0u;
+        if (tid < BQ) { Qa_[bi][tid] = Aug<T>::x(-lse_r); Da_[bi][tid] = Aug<T>::x(ndc_r); ndc_s_[bi][tid] = ndc_r; }
+    };
+    if (q_beg < q_end) prefetch(q_beg);
+    if constexpr (NBUF == 2) {
+        if (q_beg < q_end) {
+            commit(0);
+            if (q_beg + BQ < q_end) prefetch(q_beg + BQ);
         }
-        if (q0 + BQ < q_end) prefetch(q0 + BQ);
+        __syncthreads();
+    }
+    int buf = 0;
+    for (int q0 = q_beg; q0 < q_end; q0 += BQ) {
+        uint32_t wbits[BQ / 32];
+        auto load_bits = [&]() {
+#pragma unroll
+            for (int mb = 0; mb < BQ / 32; ++mb) {              // requested ahead of the next tile's rows: vmcnt is in order
+                const int qb32 = min((q0 >> 5) + mb, nqb32 - 1);
+                wbits[mb] = DROP ? wcol[qb32 * wq_stride] >> (4 * hh) : 0u;
+            }
+        };
+        if constexpr (NBUF == 2) {
+            if (q0 + BQ < q_end) commit(buf ^ 1);
+            load_bits();
+            if (q0 + 2 * BQ < q_end) prefetch(q0 + 2 * BQ);
+        } else {
+            __syncthreads();
+            commit(0);
+            __syncthreads();
+            load_bits();
+            if (q0 + BQ < q_end) prefetch(q0 + BQ);
+        }
+        T* const Qs = Qs_[buf];
+        T* const Ds = Ds_[buf];
+        F* const Qa = Qa_[buf];
+        F* const Da = Da_[buf];
+        float* const ndc_s = ndc_s_[buf];
 #pragma unroll
         for (int mb = 0; mb < BQ / 32; ++mb) {
             const int qb = q0 + mb * 32;
@@ -911,6 +987,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a, const 
                 }
             }
         }
+        if constexpr (NBUF == 2) { __syncthreads(); buf ^= 1; }
     }
     // accumulators: column = d (lane & 31), row = key (register axis)
     const float ksc = a.scale * a.drop_scale;
