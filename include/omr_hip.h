@@ -198,6 +198,10 @@ int omr_conv3x3_bwd_fused(const void* g, const void* x, const void* w_flipped, v
                           int COUT, int mask_input, float mask_scale, const void* norm_y, const float* norm_mean, const float* norm_rstd,
                           const void* norm_workspace, int norm_slots, int relu_mask, float relu_scale, const float* x_mean, const float* x_rstd,
                           void* stat_workspace, int stat_slots, void* stream);
+/* The same for the stride-(2,2) normalise-on-load conv with 32 -> 32 channels (ConvBlock 1's conv3, encoder.py:132-156): g is the
+ * gradient of the [ceil(H/2)][ceil(W/2)] output, x the [H][W] input, dx = dL/dxhat with the InstanceNorm-backward sums in the slots. */
+int omr_conv3x3_bwd_fused_s2(const void* g, const void* x, const void* w_flipped, void* dx, float* dw, float* db, int B, int H, int W,
+                             const float* x_mean, const float* x_rstd, void* stat_workspace, int stat_slots, void* stream);
 /* depthwise 3x3, stride 1, pad 1 (DepthSepConv2D.depth_conv, encoder.py:56-64); flip=1 mirrors the taps (data gradient) */
 int omr_dwconv3x3(int dtype, const void* x, const void* w, const float* bias, void* y, const float* in_mean, const float* in_rstd,
                   const void* out_mask, float mask_scale, int B, int H, int W, int C, int flip, void* stream);

@@ -525,6 +525,275 @@ template <bool APPLY> int pick(const FusedArgs& a, int CO, int CI, hipStream_t s
     return OMR_ERR_UNSUPPORTED;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Stride (2, 2): ConvBlock 1's conv3 (32 -> 32 channels, InstanceNorm applied on load).  Same workgroup, ring and roles; what changes
+// is the geometry.  The tile is 8 x 32 pixels of the FULL-resolution input X (= of the outgoing gradient dL/dxhat); the gradient G
+// of the half-resolution output contributes through  q = 2 p + k - 1:  pixel q of X meets tap k = (kh, kw) iff q + 1 - k is even,
+// at p = (q + 1 - k) / 2 -- rows 4t .. 4t + 4, columns 16 tw .. 16 tw + 16 of G: a 5 x 17 halo tile.
+//   * data gradient: a wave owns one tile row, so the row parity fixes the tap rows (even rows: kh = 1; odd rows: kh = 0, 2) for the
+//     whole wave; the column parity differs lane by lane, so a tap column's MFMA carries the G fragment only in the lanes of its parity
+//     (zeros in the others: kw = 1 on even columns, kw = 0 / 2 on odd ones) -- 6 or 12 MFMAs per row instead of 18, no dilated zeros staged;
+//   * weight gradient: K = the X pixels of ONE column parity of a row (16 pixels, read from LDS at pixel stride 2) against 16 consecutive
+//     G pixels; tap (kh, kw) meets exactly four such slabs per tile (rows of its parity x its column parity): wave w owns tap w, tap 8
+//     and the bias sums (the tile's own 4 x 16 G pixels against ones) are one slab per wave;
+//   * X is normalised in LDS and the InstanceNorm-backward sums of the outgoing gradient are reduced as in the stride-1 XN mode.
+struct S2 {
+    static constexpr int GH = TH / 2 + 1, GW = TW / 2 + 1, NG = GH * GW;
+    typedef Issuer<32, GW, NG> IG;
+    typedef Issuer<32, TW, NCORE> IX;
+    static constexpr int NSLOT = 4, GB = IG::BYTES, XB = IX::BYTES, SLOT = GB + XB, WP = 40 * 2, WS = 32 * 9 * WP;
+    static constexpr int OFF_WS = NSLOT * SLOT, OFF_SCRATCH = OFF_WS + WS, TOTAL = OFF_SCRATCH + 1024;
+    static constexpr int DPT_WG = IG::ROUNDS, DPT_DG = IX::ROUNDS;
+};
+
+template <bool DG>
+__device__ __forceinline__ void tile_loop_s2(const FusedArgs& a, unsigned char* smem, const float* cst) {
+    typedef Tile<32> T32;
+    constexpr int NSLOT = S2::NSLOT, GW = S2::GW, WP = S2::WP, XCPP = 4;
+    constexpr bool WG = !DG;
+    constexpr int VM_ALLOWED = DG ? (NSLOT - 2) * S2::DPT_DG + (NSLOT - 1) * XCPP : (NSLOT - 2) * S2::DPT_WG;
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.z;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
+    const int wtid = tid & 511;
+    const int frow = lane & 31, h = lane >> 5;
+    const unsigned char* Ws = smem + S2::OFF_WS;
+    const unsigned lds0 = lds_address(smem);
+    const int Ho = (a.H + 1) / 2, Wo = (a.W + 1) / 2;
+    const bf16* G = a.g + (long)b * Ho * Wo * 32;
+    const bf16* X = a.x + (long)b * a.H * a.W * 32;
+    bf16* DX = a.dx + (long)b * a.H * a.W * 32;
+
+    S2::IG ig;
+    S2::IX ix;
+    if constexpr (WG) ig.init(Wo, wtid);
+    if constexpr (DG) ix.init(a.W, wtid);
+    const int step_h = (int)gridDim.x / a.tiles_w, step_w = (int)gridDim.x - step_h * a.tiles_w;
+    auto advance = [&](int& th, int& tw) {
+        th += step_h; tw += step_w;
+        if (tw >= a.tiles_w) { tw -= a.tiles_w; ++th; }
+    };
+    auto issue = [&](int th, int tw, int slot) {
+        const bool live = th < a.tiles_h;
+        const int oh0 = live ? th * TH : -(1 << 20), ow0 = tw * TW;
+        const int ph0 = live ? th * (TH / 2) : -(1 << 20), pw0 = tw * (TW / 2);
+        const unsigned base = lds0 + (unsigned)(slot * S2::SLOT), scratch = lds0 + (unsigned)S2::OFF_SCRATCH;
+        if constexpr (WG) {
+            const bool in_g = live && ph0 + S2::GH <= Ho && pw0 + GW <= Wo;
+            ig.issue(G + ((long)ph0 * Wo + pw0) * 32, ph0, pw0, Ho, Wo, in_g, base, scratch, wtid);
+        }
+        if constexpr (DG) {
+            const bool in_x = live && oh0 + TH <= a.H && ow0 + TW <= a.W;
+            ix.issue(X + ((long)oh0 * a.W + ow0) * 32, oh0, ow0, a.H, a.W, in_x, base + (unsigned)S2::GB, scratch, wtid);
+        }
+    };
+    bf16* const sink = reinterpret_cast<bf16*>(g_store_sink) + 4 * (lane >> 5);
+    auto dummy_stores = [&]() {
+        if constexpr (DG) {
+            typedef __attribute__((ext_vector_type(4))) bf16 B4;
+            const B4 z = {0, 0, 0, 0};
+#pragma unroll
+            for (int g4 = 0; g4 < XCPP; ++g4) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(sink), "v"(z) : "memory");
+        }
+    };
+
+    // ---- data gradient: row `wave` of the tile; tap rows by the row's parity, tap columns by the lane's
+    const bool row_odd = wave & 1;
+    const int woff = frow * 9 * WP + h * 16;
+    int dgo[3];                              // G fragment of tap column kw for THIS lane (valid where its column parity takes that tap), row 0 of the G tile
+    bool dga[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int num = frow + 1 - kw;       // = 2 * (G column inside the tile) where the parity fits
+        dga[kw] = (num & 1) == 0;
+        const int pc = dga[kw] ? num >> 1 : 0;
+        dgo[kw] = T32::chunk(pc, pc, h);
+    }
+    // ---- weight gradient: tap `wave` (kh, kw) over its four slabs; second accumulator: one slab of tap 8 (waves 0-3) / of the bias sums (waves 4-7)
+    const int q = (lane & 15) >> 2, p = lane & 3, cb = (lane >> 4) & 1;
+    const int wkh = wave / 3, wkw = wave - 3 * wkh;
+    const bool third_bias = wave >= 4;
+    const bool third = !third_bias || a.db != nullptr;
+    // lane's K index j = 8 h + q (+4): X pixel column 2 j + cp, G pixel column j + dcol
+    auto slab_offsets = [&](int kw, int (&xo)[2], int (&go)[2]) {
+        const int cp = kw == 1 ? 0 : 1, dcol = (cp + 1 - kw) >> 1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = 8 * h + q + 4 * u;
+            xo[u] = T32::tr(2 * j + cp, 2 * j + cp, cb, p);
+            go[u] = T32::tr(dcol + j, dcol + j, cb, p);
+        }
+    };
+    int xo1[2], go1[2], xo2[2], go2[2];
+    slab_offsets(wkw, xo1, go1);
+    slab_offsets(2, xo2, go2);               // tap 8 = (2, 2)
+    int gb2[2];                              // bias: the tile's own G pixels, columns j = 0 .. 15 of a row
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int j = 8 * h + q + 4 * u; gb2[u] = T32::tr(j, j, cb, p); }
+    f32x16 wacc[WG ? 2 : 1];
+    if constexpr (WG) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wacc[j][r] = 0.f;
+    }
+    const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    float ssum[DG ? 16 : 1], ssq[DG ? 16 : 1];
+#pragma unroll
+    for (int e = 0; e < (DG ? 16 : 1); ++e) ssum[e] = ssq[e] = 0.f;
+
+    int th = (int)blockIdx.x / a.tiles_w, tw = (int)blockIdx.x - th * a.tiles_w;
+    int ith = th, itw = tw;
+#pragma unroll
+    for (int st = 0; st < NSLOT - 1; ++st) { issue(ith, itw, st); advance(ith, itw); dummy_stores(); }
+    int cur = 0;
+    for (; th < a.tiles_h; advance(th, tw), cur = (cur + 1) & (NSLOT - 1)) {
+        const int oh0 = th * TH, ow0 = tw * TW;
+        unsigned char* Gs = smem + cur * S2::SLOT;
+        unsigned char* Xt = Gs + S2::GB;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM_ALLOWED) : "memory");
+        __syncthreads();
+        issue(ith, itw, (cur + NSLOT - 1) & (NSLOT - 1));
+        advance(ith, itw);
+        {   // xhat = x * rstd - mean * rstd in place (one 16-byte chunk per thread; pixels of an overhanging tile stay 0)
+            const int pix = tid >> 2, k = tid & 3;
+            if (oh0 + (pix >> 5) < a.H && ow0 + (pix & 31) < a.W) {
+                unsigned char* px = Xt + T32::chunk(pix, pix & 31, k);
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(px);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)fmaf((float)v[e], cst[k * 8 + e], cst[32 + k * 8 + e]);
+                *reinterpret_cast<bf16x8*>(px) = v;
+            }
+        }
+        __syncthreads();
+
+        if constexpr (DG) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // G row inside the tile: (wave + 1 - kh) / 2
+            auto taps = [&](auto kh_c) {
+                constexpr int KH = decltype(kh_c)::value;
+                const int prow = (wave + 1 - KH) >> 1;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int tapf = 8 - (KH * 3 + kw);                  // index into the flipped weights
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc) {
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Ws + woff + tapf * WP + kc * 32);
+                        bf16x8 gf = *reinterpret_cast<const bf16x8*>(Gs + prow * GW * 64 + (dgo[kw] ^ (kc << 5)));
+                        if (!dga[kw]) gf = zero8;
+                        mma32(acc, wf, gf);
+                    }
+                }
+            };
+            if (row_odd) { taps(std::integral_constant<int, 0>{}); taps(std::integral_constant<int, 2>{}); }
+            else taps(std::integral_constant<int, 1>{});
+            const int oh = oh0 + wave, ow = ow0 + frow;
+            const bool inside = oh < a.H && ow < a.W;
+            bf16* drow = inside ? DX + ((long)oh * a.W + ow) * 32 + 4 * h : sink;
+            const int dstep = inside ? 8 : 0;
+            const unsigned char* xrow = Xt + 8 * h;
+#pragma unroll
+            for (int g4 = 0; g4 < XCPP; ++g4) {
+                typedef __attribute__((ext_vector_type(4))) bf16 B4;
+                B4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[4 * g4 + e];
+                asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(drow + dstep * g4), "v"(o) : "memory");
+                const B4 xh = *reinterpret_cast<const B4*>(xrow + T32::chunk(wave * TW + frow, frow, g4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float f = inside ? (float)o[e] : 0.f; ssum[4 * g4 + e] += f; ssq[4 * g4 + e] += f * (float)xh[e]; }
+            }
+        }
+        if constexpr (WG) {
+            // tap (wkh, wkw): rows of the parity that fits kh, G row (r + 1 - kh) / 2
+            auto tap_slabs = [&](auto par_c) {
+                constexpr int PAR = decltype(par_c)::value;                  // 0: even rows (kh = 1), 1: odd rows (kh = 0, 2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 2 * i + PAR;
+                    const int prow = (r + 1 - wkh) >> 1;                     // wave-uniform
+                    const bf16x8 xf = tr_frag(Xt, xo1[0], xo1[1], r * TW * 64);
+                    mma32(wacc[0], tr_frag(Gs + prow * GW * 64, go1[0], go1[1], 0), xf);
+                }
+            };
+            if (wkh == 1) tap_slabs(std::integral_constant<int, 0>{});
+            else tap_slabs(std::integral_constant<int, 1>{});
+            if (third) {
+                if (third_bias) {        // bias: G row (wave - 4) of the tile's own four rows
+                    mma32(wacc[1], tr_frag(Gs + (wave - 4) * GW * 64, gb2[0], gb2[1], 0), ones);
+                } else {                 // tap 8 = (2, 2): odd rows r = 2 wave + 1, G row (r - 1) / 2 = wave
+                    const int r = 2 * wave + 1;
+                    const bf16x8 xf = tr_frag(Xt + r * TW * 64, xo2[0], xo2[1], 0);
+                    mma32(wacc[1], tr_frag(Gs + wave * GW * 64, go2[0], go2[1], 0), xf);
+                }
+            }
+        }
+    }
+    dma_drain();
+    {   // deterministic reduction of the InstanceNorm-backward sums (see the stride-1 XN mode)
+        float* red = reinterpret_cast<float*>(smem);          // [2][32][256]
+        __syncthreads();
+        if constexpr (DG) {
+            const int j = wave * 32 + frow;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 8 * g4 + 4 * h + e;
+                    red[c * 256 + j] = ssum[4 * g4 + e];
+                    red[(32 + c) * 256 + j] = ssq[4 * g4 + e];
+                }
+        }
+        __syncthreads();
+        if (DG && tid < 64) {
+            const int k = tid >> 5, c = tid & 31;
+            double acc2 = 0.0;
+            for (int j = 0; j < 256; ++j) acc2 += (double)red[(k * 32 + c) * 256 + j];
+            a.stat_ws[(((long)b * a.stat_slots + blockIdx.x) * 32 + c) * 2 + k] = acc2;
+            if (blockIdx.x == 0)
+                for (int sl = gridDim.x; sl < a.stat_slots; ++sl) a.stat_ws[(((long)b * a.stat_slots + sl) * 32 + c) * 2 + k] = 0.0;
+        }
+    }
+    if constexpr (WG) {
+        const int tapw = third_bias ? -1 : 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j == 1 && (third_bias || !third)) break;
+            const int tap = j == 0 ? wave : tapw;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = acc_row(r, lane), ci = lane & 31;
+                atomicAdd(&a.dw[((long)co * 9 + tap) * 32 + ci], wacc[j][r]);
+            }
+        }
+        if (third_bias && a.db != nullptr && (lane & 31) == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) atomicAdd(&a.db[acc_row(r, lane)], wacc[1][r]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void conv_bwd_fused_s2_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ __attribute__((aligned(16))) float cst[2 * 32];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    unsigned char* Ws = smem + S2::OFF_WS;
+    for (int c = tid; c < 32 * 9 * 4; c += 1024) {
+        const int row = c >> 2, kc = c & 3;
+        *reinterpret_cast<bf16x8*>(Ws + row * S2::WP + kc * 16) = *reinterpret_cast<const bf16x8*>(a.w + (long)row * 32 + kc * 8);
+    }
+    if (tid < 32) {
+        const float rs = a.xrstd[(long)b * 32 + tid], mu = a.xmean[(long)b * 32 + tid];
+        cst[tid] = rs; cst[32 + tid] = -mu * rs;
+    }
+    __syncthreads();
+    if (tid < NDG) tile_loop_s2<true>(a, smem, cst);
+    else tile_loop_s2<false>(a, smem, cst);
+}
+
 }  // namespace
 
 extern "C" int omr_conv3x3_bwd_fused(const void* g, const void* x, const void* w_flipped, void* dx, float* dw, float* db, int B, int H, int W, int CIN,
@@ -563,3 +832,27 @@ extern "C" int omr_fused_prof_read(unsigned long long* out16, int reset) {
     return OMR_OK;
 }
 #endif
+
+extern "C" int omr_conv3x3_bwd_fused_s2(const void* g, const void* x, const void* w_flipped, void* dx, float* dw, float* db, int B, int H, int W,
+                                        const float* x_mean, const float* x_rstd, void* stat_workspace, int stat_slots, void* stream) {
+    if (!g || !x || !w_flipped || !dx || !dw || !x_mean || !x_rstd || !stat_workspace || B <= 0 || H <= 0 || W <= 0 || stat_slots < 1) return OMR_ERR_ARG;
+    if ((((uintptr_t)g) | ((uintptr_t)x)) & 15) return OMR_ERR_UNSUPPORTED;
+    if ((long)(IH + 1) * W * 32 >= (1L << 30)) return OMR_ERR_UNSUPPORTED;
+    FusedArgs a{};
+    a.g = (const bf16*)g; a.x = (const bf16*)x; a.w = (const bf16*)w_flipped; a.dx = (bf16*)dx; a.dw = dw; a.db = db;
+    a.B = B; a.H = H; a.W = W; a.xmean = x_mean; a.xrstd = x_rstd; a.stat_ws = (double*)stat_workspace; a.stat_slots = stat_slots;
+    a.tiles_w = cdiv(W, TW); a.tiles_h = cdiv(H, TH);
+    static std::atomic<int> ready{0};
+    if (ready.load(std::memory_order_acquire) == 0) {
+        if (hipFuncSetAttribute((const void*)conv_bwd_fused_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S2::TOTAL) != hipSuccess) return OMR_ERR_LAUNCH;
+        ready.store(1, std::memory_order_release);
+    }
+    const long tiles_per_img = (long)a.tiles_w * a.tiles_h;
+    long gx = (256 + B - 1) / B;
+    if (gx > tiles_per_img) gx = tiles_per_img;
+    if (gx > stat_slots) gx = stat_slots;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(conv_bwd_fused_s2_kernel, dim3((unsigned)gx, 1, B), dim3(1024), S2::TOTAL, (hipStream_t)stream, a);
+    OMR_CHECK_LAUNCH();
+    return OMR_OK;
+}

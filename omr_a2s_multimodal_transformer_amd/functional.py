@@ -35,8 +35,8 @@ TWO_PASS_NORM_BWD = False
 # kernel (the operands of the weight gradient are the tiles the data gradient already holds), bit 2 = the InstanceNorm backward of the
 # layer above applied while that kernel loads its tile (ConvBlock conv2 <- norm <- conv3: conv3's backward hands its un-applied
 # gradient on, conv2's backward consumes it; no omr_instnorm_bwd_apply launch, its output is never written), bit 4 = the one-pass form
-# of the 16-channel normalise-on-load conv (ConvBlock 0's conv3).
-FUSED_BWD = int(os.environ.get("OMR_FUSED_BWD", "7"))
+# of the 16-channel normalise-on-load conv (ConvBlock 0's conv3), bit 8 = of the 32-channel stride-(2,2) one (ConvBlock 1's conv3).
+FUSED_BWD = int(os.environ.get("OMR_FUSED_BWD", "15"))
 FUSED_NORM_CHANNELS = tuple(int(c) for c in os.environ.get("OMR_FUSED_NORM_CHANNELS", "16,32").split(",") if c)   # conv2 widths that take the hand-on
 FUSED_MIN_COUT = int(os.environ.get("OMR_FUSED_MIN_COUT", "16"))
 _PENDING_NORM = {}        # data_ptr of a handed-on gradient -> (y, mean, rstd, ws, slots, relu_mask, relu_scale); consumed by the producer conv's backward
@@ -129,6 +129,10 @@ class Conv3x3Fn(Function):
         # InstanceNorm-backward sums
         one_pass_norm = (bool(FUSED_BWD & 4) and stats is not None and ctx.needs_input_grad[0] and tuple(stride) == (1, 1)
                          and x.shape[-1] == 16 and g.shape[-1] == 16 and K.conv3x3_bwd_fused_ok(x, g, stride))
+        # ... and of the 32-channel one with stride (2, 2) (ConvBlock 1's conv3)
+        one_pass_s2 = (bool(FUSED_BWD & 8) and stats is not None and ctx.needs_input_grad[0] and tuple(stride) == (2, 2) and x.dtype == torch.bfloat16
+                       and x.shape[-1] == 32 and g.shape[-1] == 32)
+        one_pass_norm = one_pass_norm or one_pass_s2
         # one workgroup per CU with a full LDS ring: little can run beside it, but its ramp-up / drain overlaps the data gradient's
         # (28.37 -> 28.17 ms per C2 step; a shallower ring that leaves LDS for the neighbour loses more than it gains: 28.4)
         if not one_pass_norm:
@@ -145,7 +149,9 @@ class Conv3x3Fn(Function):
                 ws, slots = K.conv_stat_ws(x.shape[0], H, W, x.shape[3], x.device)
                 kw = dict(stride=(1, 1), dil=stride, out_hw=(H, W), stat_ws=ws, stat_slots=slots, stat_x=x, stat_stats=stats)
                 if ctx.norm_bwd == 1 or one_pass_norm:
-                    if one_pass_norm:
+                    if one_pass_s2:
+                        dxh = K.conv3x3_bwd_fused_s2(g, x, wd, weight.omr_grad, bias.omr_grad, stats[0], stats[1], ws, slots)
+                    elif one_pass_norm:
                         dxh = K.conv3x3_bwd_fused(g, x, wd, weight.omr_grad, bias.omr_grad, False, 1.0, xnorm=(stats[0], stats[1], ws, slots))
                     else:
                         dxh = K.conv3x3(g, wd, None, stat_mode=2, **kw)

@@ -535,6 +535,21 @@ def conv3x3_bwd_fused(g: Tensor, x: Tensor, w_flipped: Tensor, dw_phys: Tensor, 
     return dx
 
 
+def conv3x3_bwd_fused_s2(g: Tensor, x: Tensor, w_flipped: Tensor, dw_phys: Tensor, db: Optional[Tensor], mean: Tensor, rstd: Tensor, ws: Tensor,
+                         slots: int) -> Tensor:
+    """One-pass backward of the stride-(2,2), 32 -> 32 channel conv that normalised x on load (bf16): returns dL/dxhat, accumulates
+    dw_phys / db and fills the InstanceNorm-backward slots of ws (conv_stat_ws layout for x's shape)."""
+    require_cuda(g, x, w_flipped, dw_phys, db, mean, rstd, ws)
+    B, H, W, C = x.shape
+    assert C == 32 and x.dtype == torch.bfloat16 and g.dtype == x.dtype and tuple(g.shape) == (B, (H + 1) // 2, (W + 1) // 2, 32)
+    assert g.is_contiguous() and x.is_contiguous() and tuple(w_flipped.shape) == (32, 3, 3, 32) and w_flipped.is_contiguous() and w_flipped.dtype == x.dtype
+    assert dw_phys.dtype == torch.float32 and dw_phys.is_contiguous() and tuple(dw_phys.shape) == (32, 3, 3, 32) and ws.dtype == torch.float64
+    dx = torch.empty_like(x)
+    lib().call("omr_conv3x3_bwd_fused_s2", ptr(g), ptr(x), ptr(w_flipped), ptr(dx), ptr(dw_phys), ptr(db), B, H, W, ptr(mean), ptr(rstd), ptr(ws), int(slots),
+               cur_stream())
+    return dx
+
+
 def dwconv3x3(x: Tensor, w: Tensor, bias: Optional[Tensor], in_stats=None, out_mask: Optional[Tensor] = None, mask_scale: float = 1.0,
               flip: bool = False) -> Tensor:
     """Depthwise 3x3 on NHWC; w is [C,9] (= [C,1,3,3] storage)."""

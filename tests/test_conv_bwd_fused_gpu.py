@@ -142,3 +142,42 @@ def test_fused_backward_of_the_normalise_on_load_conv(B, H, W):
     assert float((a0.float() - a1.float()).abs().max()) <= 1e-2 * float(a0.float().abs().max())
     assert float((dw - dw0).abs().max()) <= 4e-3 * float(dw0.abs().max())
     assert float((db - db0).abs().max()) <= 2e-3 * float(db0.abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 24, 96), (3, 16, 64), (1, 13, 70), (2, 9, 33)])
+def test_fused_backward_of_the_strided_normalise_on_load_conv(B, H, W):
+    """omr_conv3x3_bwd_fused_s2: ConvBlock 1's conv3 (32 -> 32, stride (2, 2), InstanceNorm applied on load).  Against the separate kernels
+    -- omr_conv3x3_fwd as the zero-dilated data gradient with stat_mode 2, omr_conv3x3_wgrad with stride and in_stats -- on the same
+    bf16 operands: data gradient equal to a bf16 rounding (odd sizes included: tiles that overhang, a last output row / column that
+    sees one input row / column), sums to 3e-3 of the largest, weight / bias gradients to 4e-3."""
+    c = 32
+    gen = torch.Generator().manual_seed(500 + H)
+    x = torch.randn((B, H, W, c), generator=gen)
+    x = torch.where(x < 0, torch.zeros_like(x), x).to(BF)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    g = (torch.randn((B, Ho, Wo, c), generator=gen) * 0.5).to(BF)
+    w = (torch.randn((c, 3, 3, c), generator=gen) * 0.2).to(BF)
+    xd, gd, wf = x.to(DEV), g.to(DEV), K.conv3x3_weight_flip(w.to(DEV))
+    mean, rstd = K.instnorm_stats(xd)
+    ws0, slots = K.conv_stat_ws(B, H, W, c, DEV)
+    dx0 = K.conv3x3(gd, wf, None, stride=(1, 1), dil=(2, 2), out_hw=(H, W), stat_mode=2, stat_ws=ws0, stat_slots=slots, stat_x=xd, stat_stats=(mean, rstd))
+    dw0 = torch.zeros((c, 3, 3, c), device=DEV)
+    db0 = torch.zeros(c, device=DEV)
+    K.conv3x3_wgrad(xd, gd, dw0, stride=(2, 2), in_stats=(mean, rstd), db=db0)
+    ws, _ = K.conv_stat_ws(B, H, W, c, DEV)
+    ws.view(-1).fill_(77.0)
+    dw = torch.zeros_like(dw0)
+    db = torch.zeros_like(db0)
+    dx = K.conv3x3_bwd_fused_s2(gd, xd, wf, dw, db, mean, rstd, ws, slots)
+    torch.cuda.synchronize()
+    # (the two kernels sum the taps in different orders: equal to a bf16 rounding, not to the bit)
+    assert float((dx.float() - dx0.float()).abs().max()) <= 8e-3 * float(dx0.float().abs().max())
+    assert float((dx.float() - dx0.float()).norm() / dx0.float().norm()) < 2e-3
+    K.instnorm_bwd_apply(dx0, xd, mean, rstd, ws0, slots, True, 1.0)
+    K.instnorm_bwd_apply(dx, xd, mean, rstd, ws, slots, True, 1.0)
+    torch.cuda.synchronize()
+    n = B * slots * c * 2
+    s0, s1 = ws0.view(-1)[n:n + B * c * 2], ws.view(-1)[n:n + B * c * 2]
+    assert float((s0 - s1).abs().max()) <= 3e-3 * float(s0.abs().max()) + 1e-6
+    assert float((dw - dw0).abs().max()) <= 4e-3 * float(dw0.abs().max())
+    assert float((db - db0).abs().max()) <= 2e-3 * float(db0.abs().max()) + 1e-4

@@ -61,3 +61,17 @@ t_f = timed(lambda: K.conv3x3_bwd_fused(g, x, wf, dw, db, False, 1.0, xnorm=(mea
 t_d = timed(lambda: K.conv3x3(g, wf, None, out_hw=(H, W), stat_mode=2, stat_ws=ws, stat_slots=slots, stat_x=x, stat_stats=(mean, rstd)))
 t_w = timed(lambda: K.conv3x3_wgrad(x, g, dw, in_stats=(mean, rstd), db=db))
 print(f"normalise-on-load 16 -> 16: fused {t_f:7.1f} us   dgrad + sums {t_d:7.1f} + wgrad {t_w:7.1f} = {t_d + t_w:7.1f} us", flush=True)
+
+# the strided normalise-on-load form (32 -> 32, stride 2): against the zero-dilated data gradient + sums and the strided weight gradient
+x = torch.rand((B, H, W, 32), device=dev).sub_(0.4).clamp_min_(0).to(torch.bfloat16)
+g = torch.randn((B, H // 2, W // 2, 32), device=dev).mul_(0.1).to(torch.bfloat16)
+w = (torch.rand((32, 3, 3, 32), device=dev) - 0.5).to(torch.bfloat16)
+wf = K.conv3x3_weight_flip(w)
+dw = torch.zeros((32, 3, 3, 32), device=dev)
+db = torch.zeros(32, device=dev)
+mean, rstd = K.instnorm_stats(x)
+ws, slots = K.conv_stat_ws(B, H, W, 32, dev)
+t_f = timed(lambda: K.conv3x3_bwd_fused_s2(g, x, wf, dw, db, mean, rstd, ws, slots))
+t_d = timed(lambda: K.conv3x3(g, wf, None, stride=(1, 1), dil=(2, 2), out_hw=(H, W), stat_mode=2, stat_ws=ws, stat_slots=slots, stat_x=x, stat_stats=(mean, rstd)))
+t_w = timed(lambda: K.conv3x3_wgrad(x, g, dw, stride=(2, 2), in_stats=(mean, rstd), db=db))
+print(f"strided normalise-on-load 32 -> 32: fused {t_f:7.1f} us   dgrad + sums {t_d:7.1f} + wgrad {t_w:7.1f} = {t_d + t_w:7.1f} us", flush=True)
