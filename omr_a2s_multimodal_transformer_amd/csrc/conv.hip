@@ -439,18 +439,19 @@ __global__ __launch_bounds__(256) void conv1_wgrad_mfma_kernel(const bf16* __res
     const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const int ntiles = B * tiles_h * tiles_w;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // global -> registers: two 16-byte dY chunks per thread (pixel tid / 2 + 128 j, chunk tid % 2) and up to four image halo values; the
+    // next tile's loads are issued before the current tile's MFMAs
+    bf16x8 gv[2];
+    bf16 xv[4];
+    auto load_tile = [&](int tile) {
         const int b = tile / (tiles_h * tiles_w), rem = tile - b * tiles_h * tiles_w;
         const int th = rem / tiles_w, tw = rem - th * tiles_w, oh0 = th * TH1, ow0 = tw * TW1;
-        // global -> registers: two 16-byte dY chunks per thread (pixel tid / 2 + 128 j, chunk tid % 2), image halo values
-        bf16x8 gv[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int pix = (tid >> 1) + 128 * j, oh = oh0 + (pix >> 5), ow = ow0 + (pix & 31);
             gv[j] = zero8;
             if (oh < H && ow < Wd) gv[j] = *reinterpret_cast<const bf16x8*>(dy + (((long)b * H + oh) * Wd + ow) * 16 + (tid & 1) * 8);
         }
-        bf16 xv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                  // shifted copies: 3 x 10 x 32 = 960 values
             const int e = tid + 256 * j, sft = e / (IH1 * TW1), r = (e / TW1) % IH1, c = e % TW1;
@@ -458,6 +459,9 @@ __global__ __launch_bounds__(256) void conv1_wgrad_mfma_kernel(const bf16* __res
             xv[j] = (bf16)0.f;
             if (e < 3 * IH1 * TW1 && ih >= 0 && ih < H && iw >= 0 && iw < Wd) xv[j] = x[((long)b * H + ih) * Wd + iw];
         }
+    };
+    if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();                               // the previous tile's MFMAs are done with the LDS tiles
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -470,6 +474,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_mfma_kernel(const bf16* __res
             if (e < 3 * IH1 * TW1) Xs[sft][r][c] = xv[j];
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const int row = wave * 2 + (s4 >> 1), col0 = (s4 & 1) * 16;
@@ -1053,7 +1058,7 @@ extern "C" int omr_conv3x3_wgrad(int dtype, const void* x, const void* dy, float
         if (dtype == OMR_BF16 && COUT == 16 && (((uintptr_t)dy) & 15) == 0) {
             const int th = cdiv(H, 8), tw = cdiv(W, 32);
             long nt = (long)B * th * tw;
-            const int nblk = (int)(nt < 256 * 6 ? nt : 256 * 6);           // persistent: each workgroup ends with 160 atomics onto the same cache lines
+            const int nblk = (int)(nt < 256 * 8 ? nt : 256 * 8);           // persistent (8 workgroups per CU): each ends with 160 atomics onto the same cache lines
             hipLaunchKernelGGL(conv1_wgrad_mfma_kernel, dim3(nblk), dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, dw, db, B, H, W, th, tw);
             OMR_CHECK_LAUNCH();
             return OMR_OK;
