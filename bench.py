@@ -375,7 +375,7 @@ def roofline_others(B, H, W, T, d, nhead):
     res.append({"kernel": "attn_fwd_kernel (cross-attention of one decoder layer, dropout 0.1 + key bias)", "bound": "mfma", "avg_launch_ms": round(ms, 4),
                 "algorithmic_flops": fl, "achieved": round(fl / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / MFMA_BF16_PEAK_TF, 4)})
     ms = _timed(lambda: K.attn_bwd(q, k, v, o, do, lse, dq, dkv[..., :d], dkv[..., d:], nhead, **kw))
-    res.append({"kernel": "attn_delta + attn_bwd_dq + attn_bwd_dkv (the same layer's backward)", "bound": "mfma", "avg_launch_ms": round(ms, 4),
+    res.append({"kernel": "attn_bwd_dq (forms delta) + attn_bwd_dkv (the same layer's backward)", "bound": "mfma", "avg_launch_ms": round(ms, 4),
                 "algorithmic_flops": 2.5 * fl, "achieved": round(2.5 * fl / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(2.5 * fl / ms / 1e9 / MFMA_BF16_PEAK_TF, 4)})
     del q, kv, o, do, dq, dkv, words

@@ -515,21 +515,6 @@ __global__ __launch_bounds__(64) void attn_split_merge_kernel(AttnArgs a) {
     if (dch == 0 && a.lse) a.lse[((long)b * a.H + h) * a.T + q] = (l_tot > 0.f) ? (mm + log2f(l_tot)) * LN2 : -INFINITY;
 }
 
-// delta[b][h][q] = sum_d dO[q][h*HD+d] * O[q][h*HD+d]
-template <typename T, int HD>
-__global__ void attn_delta_kernel(AttnArgs a) {
-    const long n = (long)a.B * a.H * a.T;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % a.T); const long bh = i / a.T; const int h = (int)(bh % a.H); const long b = bh / a.H;
-        const T* o = (const T*)a.o + b * a.bso + (long)q * a.ldo + h * HD;
-        const T* g = (const T*)a.dout + b * a.bsdo + (long)q * a.lddo + h * HD;
-        float s = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < HD; ++d) s += to_f32(o[d]) * to_f32(g[d]);
-        ((float*)a.delta)[i] = s;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Backward, dQ.  Same orientation as the forward: lane = query row.  c = 1 / (1 - p_drop), M = keep mask:
 //   S'^T = K Q~^T + bias - lse  (augmented k-step) ; P^T = exp2(S'^T) ; dP'^T = V dO^T - delta / c  (augmented k-step)
@@ -572,7 +557,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a, const u
     const long sidx = ((long)b * a.H + h) * a.T + q;
     float lse2 = q < a.T ? a.lse[sidx] * LOG2E : 0.f;
     if (!(lse2 > -INFINITY)) lse2 = 0.f;                        // a row without a visible key: every P is zeroed by its mask below
-    const float ndc = q < a.T ? -a.delta[sidx] / a.drop_scale : 0.f;      // -delta / c
+    // delta[q] = sum_d dO[q][d] * O[q][d] is formed HERE (the two lanes of a row hold the two halves of its d values) and stored for
+    // the dK/dV kernel that follows on the stream -- a separate pass over O and dO was a launch of its own per layer
+    float dlt = 0.f;
+    {
+        const T* O = (const T*)a.o + (long)b * a.bso + h * HD;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const F of = q < a.T ? *reinterpret_cast<const F*>(O + (long)q * a.ldo + ks * KS + hh * VEC) : frag_zero<T>();
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dlt += to_f32(of[e]) * to_f32(dof[ks][e]);
+        }
+        dlt += __shfl_xor(dlt, 32, 64);
+        if (hh == 0 && q < a.T && ksplit == 0) const_cast<float*>(a.delta)[sidx] = dlt;
+    }
+    const float ndc = -dlt / a.drop_scale;                      // -delta / c
     const bool win_on = a.window > 0 && a.window < a.T;
     int lq = -1, lkv = 0;
     if (a.blk_lq) { const int bb = (b * a.H + h) % a.B; lq = a.blk_lq[bb]; lkv = a.blk_lkv[bb]; }
@@ -1059,8 +1058,6 @@ template <typename T, int HD> int run_fwd(const AttnArgs& a, hipStream_t s, bool
     return OMR_OK;
 }
 template <typename T, int HD> int run_bwd(const AttnArgs& a, hipStream_t s) {
-    long n = (long)a.B * a.H * a.T;
-    hipLaunchKernelGGL((attn_delta_kernel<T, HD>), cdiv(n, 256), dim3(256), 0, s, a);
     const dim3 gq(cdiv(a.T, 128) * (a.nsplit > 1 ? a.nsplit : 1), a.H, a.B);
     if (a.drop_thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD, true>), gq, dim3(256), 0, s, a, a.dmask);
     else hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD, false>), gq, dim3(256), 0, s, a, a.dmask);

@@ -24,4 +24,4 @@ for p in (0.0, 0.1):
         dk, dv = dkv[..., :d], dkv[..., d:]
         t_f = timeit(lambda: K.attn_fwd(q, k, v, H, key_bias=bias, dropout_p=p, seed=7, drop_words=words), 10)
         t_b = timeit(lambda: K.attn_bwd(q, k, v, o, do, lse, dq, dk, dv, H, key_bias=bias, dropout_p=p, seed=7, drop_words=words), 10)
-        print(f"p={p} bias={'y' if bias is not None else 'n'}: fwd {t_f:6.1f} us ({flops / t_f / 1e6:5.0f} TF/s)   bwd (delta+dq+dkv) {t_b:6.1f} us ({2.5 * flops / t_b / 1e6:5.0f} TF/s)", flush=True)
+        print(f"p={p} bias={'y' if bias is not None else 'n'}: fwd {t_f:6.1f} us ({flops / t_f / 1e6:5.0f} TF/s)   bwd (dq+dkv) {t_b:6.1f} us ({2.5 * flops / t_b / 1e6:5.0f} TF/s)", flush=True)
