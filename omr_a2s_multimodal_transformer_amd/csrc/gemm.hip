@@ -66,6 +66,7 @@ __device__ __forceinline__ void mma32(f32x16& acc, u8x16 a, u8x16 b) {
 }
 
 int omr_gemm_panel_bf16(const GemmArgs& g, hipStream_t s);      // gemm_panel.hip
+int omr_gemm_tall_bf16(const GemmArgs& g, hipStream_t s);       // gemm_tall.hip
 
 namespace {
 
@@ -468,6 +469,11 @@ extern "C" int omr_gemm(int dtype, int c_dtype, int transA, int transB, int M, i
         !(lda % 8) && !(ldb % 8)) {
         // tall-and-wide output with a short reduction (the all-layer K|V projection of the memory): panel kernel, gemm_panel.hip
         const int rc = omr_gemm_panel_bf16(g, s);
+        if (rc != OMR_ERR_UNSUPPORTED) return rc;
+    }
+    if (dtype == OMR_BF16 && c_dtype == OMR_BF16 && !transA && transB && splits == 1) {
+        // tall output of 256 columns with a long reduction (the data gradient of the all-layer K|V projection): DMA-fed kernel, gemm_tall.hip
+        const int rc = omr_gemm_tall_bf16(g, s);
         if (rc != OMR_ERR_UNSUPPORTED) return rc;
     }
     if (dtype == OMR_BF16) {

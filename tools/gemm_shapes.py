@@ -49,7 +49,14 @@ def main():
         t_d = timeit(lambda: K.gemm(gy, w, trans_b=True))
         t_w = timeit(lambda: K.gemm(gy, x, trans_a=True, trans_b=True, out=gw, accumulate=True, split_k=sk, colsum_a=gb))
         tot["fwd"] += t_f * cnt; tot["dgrad"] += t_d * cnt; tot["wgrad"] += t_w * cnt
-        print(f"{name:10s} {rows:7d} {kin:5d} {nout:5d} | {t_f:8.1f} {flops / t_f / 1e6:6.0f} | {t_d:8.1f} {flops / t_d / 1e6:6.0f} | {t_w:8.1f} {flops / t_w / 1e6:6.0f} {sk}")
+        # yardstick only (never on the product path): what the vendor library does with the same forward / data-gradient shape
+        bb = bias.to(dt)
+        t_lf = timeit(lambda: torch.nn.functional.linear(x, w, bb))
+        gyc = gy.contiguous()
+        t_ld = timeit(lambda: torch.matmul(gyc, w))
+        tot.setdefault("lib fwd", 0.0); tot.setdefault("lib dgrad", 0.0)
+        tot["lib fwd"] += t_lf * cnt; tot["lib dgrad"] += t_ld * cnt
+        print(f"{name:10s} {rows:7d} {kin:5d} {nout:5d} | {t_f:8.1f} {flops / t_f / 1e6:6.0f} | {t_d:8.1f} {flops / t_d / 1e6:6.0f} | {t_w:8.1f} {flops / t_w / 1e6:6.0f} {sk} | lib fwd {t_lf:7.1f} dgrad {t_ld:7.1f}")
     print("per-step totals (ms):", {k: round(v / 1e3, 3) for k, v in tot.items()})
 
 
