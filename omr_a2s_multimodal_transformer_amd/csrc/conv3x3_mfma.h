@@ -75,8 +75,6 @@ struct ConvArgs {
 // EPI selects the fused-epilogue code that is compiled in (keeps the plain kernel's register footprint small):
 //   0 plain | 1 forward: InstanceNorm statistics of the output | 2 backward: InstanceNorm-backward sums | 3 forward: MixDropout (+ statistics)
 // (one kernel with the MixDropout code behind a run-time test was measured 7-10 % slower on the statistics-only launches, two steps in three)
-__attribute__((used)) static __device__ uint4 g_conv_store_sink[64 * 8];       // where the store loop's lanes outside the image (or of a statistics-only launch) write
-
 template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, bool SINGLE, int EPI>
 __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2) ? 4 : 3) : 2) void conv3x3_mfma_kernel(ConvArgs a) {
     typedef typename Frag<T>::type F;
@@ -289,11 +287,6 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2)
     };
     if constexpr (PF) {
         if ((int)blockIdx.x < tiles_per_img) { load_x(blockIdx.x, 0); load_w(0); }
-        // as many (sink) stores behind the first prefetch as a tile's store loop issues behind every later one: the wait in front
-        // of store_x() is then vmcnt(stores + younger loads) on every path into the loop, not vmcnt(0)
-#pragma unroll
-        for (int k = 0; k < TH * TW * CPO / 256; ++k)       // distinct addresses: the compiler must not merge them
-            *reinterpret_cast<F*>(reinterpret_cast<T*>(g_conv_store_sink) + ((k & 7) * 64 + (tid & 63)) * VEC) = frag_zero<T>();
     }
 
     for (int rem = blockIdx.x; rem < tiles_per_img; rem += gridDim.x) {
@@ -309,7 +302,7 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        for (int c0 = 0; c0 < (SINGLE ? CK : a.CIN); c0 += CK) {      // SINGLE: one trip, known at compile time
+        for (int c0 = 0; c0 < a.CIN; c0 += CK) {
             __syncthreads();                  // previous tile's store loop / previous chunk's MFMAs are done with Xs (and Ws)
             // ---- stage the input halo: thread = one halo pixel per round (ONE bounds test + address for its CPP chunks:
             //      measured 30 % faster than chunk-granular staging on the 16/32-channel layers, which are VALU-limited);
@@ -320,7 +313,7 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2)
             __syncthreads();
             if constexpr (PF) {
                 int nc0 = c0 + CK, nrem = rem;
-                if (SINGLE || nc0 >= a.CIN) { nc0 = 0; nrem = rem + gridDim.x; }
+                if (nc0 >= a.CIN) { nc0 = 0; nrem = rem + gridDim.x; }
                 if (nrem < tiles_per_img) { load_x(nrem, nc0); load_w(nc0); }
             }
             // ---- nine shifted GEMMs out of LDS
@@ -422,21 +415,15 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2)
             }
         __syncthreads();
         T* Y = (T*)a.y + (long)b * a.Ho * a.Wo * a.COUT;
-        constexpr bool MASK_OK = !(FWD && sizeof(T) == 2);      // the bf16 forward variants never carry an epilogue mask: their store loop is stores only
-        const T* Mk = MASK_OK && a.mask ? (const T*)a.mask + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
+        const T* Mk = a.mask ? (const T*)a.mask + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
         const T* SX = (stat2 || apply5) ? (const T*)a.stat_x + (long)b * a.Ho * a.Wo * a.COUT : nullptr;
 #pragma unroll(EPI == 0 ? 8 : 4)
-        for (int k = 0; k < TH * TW * CPO / 256; ++k) {   // a compile-time trip count (256 threads): see the sink note below
-            const int c = tid + k * 256;
+        for (int c = tid; c < TH * TW * CPO; c += 256) {
             const int pl = c / CPO, kc = (c % CPO) * VEC;
             const int oh = oh0 + pl / TW, ow = ow0 + pl % TW, n = n0 + kc;
-            // every lane issues every store (pixels outside the image aim at a sink): the number of vector-memory operations
-            // between the next tile's prefetch loads and their first use is then the same on every path, and the wait in front
-            // of store_x() covers the LOADS only -- with conditional stores it was vmcnt(0), i.e. also the acknowledgement of
-            // this tile's stores
-            const bool valid = oh < a.Ho && ow < a.Wo && n < a.COUT;
+            if (oh >= a.Ho || ow >= a.Wo || n >= a.COUT) continue;
             F v = *reinterpret_cast<const F*>(Os + (long)pl * OP + kc);
-            const long o = ((long)(valid ? oh : 0) * a.Wo + (valid ? ow : 0)) * a.COUT + (valid ? n : 0);
+            const long o = ((long)oh * a.Wo + ow) * a.COUT + n;
             if constexpr (DROP) {
                 if (a.drop_thresh && !a.drop_channel) {   // elementwise MixDropout after the ReLU, keyed exactly like omr_dropout by the flat NHWC index:
                     // drop_keep() of the VEC consecutive indices base .. base + VEC - 1, ONE hash per element pair (16 random bits
@@ -474,11 +461,7 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2)
                     }
                 }
             }
-            T* dst = Y + o;
-            T* const sink = reinterpret_cast<T*>(g_conv_store_sink) + (tid & 63) * VEC;
-            dst = (valid && store_y) ? dst : sink;
-            *reinterpret_cast<F*>(dst) = v;
-            if (!valid) continue;
+            if (store_y) *reinterpret_cast<F*>(Y + o) = v;
             if constexpr (FWD) {
                 if (stat1) {
 #pragma unroll
@@ -499,7 +482,6 @@ __global__ __launch_bounds__(256, (SINGLE && NT == 32) ? ((CK == 16 && EPI != 2)
 template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, bool SINGLE, int EPI> int launch_conv3(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     constexpr int TH = 4 * RPW;
-    static_assert((TH * TW * (NT / Frag<T>::N)) % 256 == 0, "the store loop covers the tile in whole rounds of 256 threads");
     constexpr int CKP = CK + Frag<T>::N;
     constexpr bool SUBPIX = conv_subpix(SH, SW, DH, DW, RPW);
     constexpr int IH = conv_halo_h(TH, SH, SUBPIX), IW = conv_halo_w(SW, SUBPIX), NPIX = IH * IW, OP = NT + Frag<T>::N;
@@ -511,7 +493,6 @@ template <typename T, int NT, int RPW, int CK, int SH, int SW, int DH, int DW, b
     if (shm > 160 * 1024) return OMR_ERR_UNSUPPORTED;
     if (a.COUT % Frag<T>::N) return OMR_ERR_UNSUPPORTED;
     if (a.mean && a.CIN > NORM_MAX) return OMR_ERR_UNSUPPORTED;
-    if (a.mask && (EPI == 1 || EPI == 3) && sizeof(T) == 2) return OMR_ERR_UNSUPPORTED;
     auto kern = conv3x3_mfma_kernel<T, NT, RPW, CK, SH, SW, DH, DW, SINGLE, EPI>;
     const int ny = cdiv(a.COUT, NT);
     const long tiles_per_img = (long)a.tiles_w * a.tiles_h;
